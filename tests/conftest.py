@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def rel_err(a, b):
+    """max-abs error normalised by the max-abs value of the expected tensor."""
+    import torch
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    denom = max(float(b.abs().max()), 1e-30)
+    return float((a - b).abs().max()) / denom
+
+
+def assert_close(a, b, tol, what=""):
+    e = rel_err(a, b)
+    assert e <= tol, "%s: normalised max error %.3e > %.1e" % (what, e, tol)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
