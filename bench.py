@@ -1,0 +1,191 @@
+"""bench.py - images/sec of one G+D training step (BASELINE.json metric) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path (loop body of the reference's main.py:142-172: D-step with three D
+forwards + one backward + Nadam, G-step with G forward + D forward + backward + Nadam) over one synthetic
+batch; workload = BASELINE.json configs[1]: 64x64 RGB, batch 64 per GPU.  Weak scaling: per-GPU batch fixed,
+gradients averaged with RCCL all-reduce.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the launch
+stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--image-size", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def conv_roofline(cfg, batch, dev, reps=10):
+    """Dominant kernel: the fp32-MFMA implicit-GEMM behind the generator's four C>=96 ConvTranspose 4x4 s2
+    stages (75 % of the step's FLOPs).  Algorithmic FLOPs per launch
+    = 2 * B * (2H * 2W) * C_out * C_in * 4 taps (each output pixel of a 4x4 s2 p1 transposed conv has 2x2 taps);
+    time = HIP events on the launch stream around `reps` launches of each stage's forward."""
+    from locate_amd import ops
+    from locate_amd.models import generator_features
+    feats = generator_features(cfg)
+    total_flops, total_ms, rows = 0.0, 0.0, []
+    size = 2
+    for i in range(len(feats) - 1):
+        c = feats[i]
+        if c >= 96 and i >= 1:
+            w = torch.randn(c, c, 4, 4, device=dev) * 0.05
+            u = torch.randn(c, device=dev)
+            v = torch.randn(c * 16, device=dev)
+            x = torch.randn(batch, c, size, size, device=dev)
+            spec = ops.ConvSpec("convT", 4, 4, 2, 1, 1)
+            pre = ops.sn_power_iteration(w, u, v)
+            with torch.no_grad():
+                for _ in range(2):
+                    ops.sn_conv(x, w, u, v, None, spec, pre)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ops.sn_conv(x, w, u, v, None, spec, pre)
+                e1.record()
+                e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            flops = 2.0 * batch * (2 * size) * (2 * size) * c * c * 4
+            rows.append({"C": c, "in": size, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2)})
+            total_flops += flops
+            total_ms += ms
+        size *= 2
+    achieved = total_flops / total_ms / 1e9 if total_ms > 0 else 0.0
+    peak = 157.3
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel (pack + fp32 MFMA implicit GEMM, ConvTranspose 4x4 s2 fwd)",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "per_stage": rows}
+
+
+def cpu_baseline(cfg, batch, steps):
+    """The CPU oracle (a port of the reference's step, parity-pinned by tests/golden) on this host's cores."""
+    from oracle import locate_oracle as O
+    from locate_amd import Discriminator, Generator
+    torch.manual_seed(999)
+    G, D = Generator(cfg), Discriminator(cfg)
+    ocfg = O.NetConfig(image_size=cfg.image_size, base_feature_factor=cfg.base_feature_factor)
+    PG = O.make_params({k: v.clone() for k, v in G.state_dict().items()})
+    PD = O.make_params({k: v.clone() for k, v in D.state_dict().items()})
+    og, od = O.Nadam(ocfg.glr, (ocfg.beta1, ocfg.beta2)), O.Nadam(ocfg.dlr, (ocfg.beta1, ocfg.beta2))
+    S = cfg.image_size
+    latent = torch.randn(batch, S)
+    real = torch.randn(batch, 3, S, S).clamp(-1, 1)
+    aug = torch.randn(batch, 3, S, S).clamp(-1, 1)
+    O.train_step(PG, PD, G.noise.clone(), og, od, latent, real, aug, ocfg)   # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        O.train_step(PG, PD, G.noise.clone(), og, od, latent, real, aug, ocfg)
+    dt = (time.time() - t0) / steps
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d warm-up + %d timed G+D steps of the same workload (%dx%d, batch %d, fp32) with the CPU oracle"
+                      % (1, steps, S, S, batch), "s_per_step": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from locate_amd import Discriminator, Generator, NetConfig, TrainStep, get_model
+    from locate_amd._lib import require_gpu
+    from locate_amd.parallel import GradAllReducer, broadcast_module_state
+    from locate_amd.graph import GraphedTrainStep
+    require_gpu()
+
+    cfg = NetConfig(image_size=args.image_size)
+    torch.manual_seed(cfg.seed)
+    G, GO = get_model(Generator(cfg), cfg.glr, dev)
+    D, DO = get_model(Discriminator(cfg), cfg.dlr, dev)
+    G.batched_spectral_norm = D.batched_spectral_norm = True
+    red_g = red_d = None
+    if world > 1:
+        broadcast_module_state(G, 0, extra_tensors=[G.noise])
+        broadcast_module_state(D, 0)
+        red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters())
+    step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d)
+    B, S = args.batch, args.image_size
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    latent = torch.randn(B, S, generator=gen).to(dev)
+    real = torch.randn(B, 3, S, S, generator=gen).clamp(-1, 1).to(dev)
+    aug = torch.randn(B, 3, S, S, generator=gen).clamp(-1, 1).to(dev)
+
+    use_graph = not args.no_graph and world == 1
+    runner = GraphedTrainStep(step, latent, real, aug, warmup=2) if use_graph else None
+
+    def one_step():
+        if runner is not None:
+            return runner.replay()
+        return step(latent, real, aug)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    d_error = float(out["d_error"])
+    g_error = float(out["g_error"])
+    assert d_error == d_error and g_error == g_error, "non-finite loss in the benchmark"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "images/sec (G+D step) 64x64 bs=64", "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (BASELINE.json configs[1]), "
+                                   "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
+                       "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
+        }
+        line["roofline"] = conv_roofline(cfg, B, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,123 @@
+/* locate_hip.h - C ABI of the MI355X (gfx950) kernels for the LocAtE generator/discriminator training step.
+ *
+ * The reference (ClashLuke/LocAtE) has no FFI: its operator boundary is the Python autograd.Function /
+ * nn.Module protocol.  Each entry point below replaces the arithmetic of one
+ * reference operator (cited per function as file:line in the reference tree) and is what a ctypes stub in
+ * the reference would bind.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers to fp32, NCHW, contiguous unless a batch stride is given;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls are asynchronous;
+ *   - every function returns 0 on success, non-zero on error (1 = bad argument, 2 = launch failure) and
+ *     never throws; locate_last_error() returns a thread-local message for the last failure;
+ *   - the library never allocates: outputs and workspaces are owned by the caller; the *_workspace_bytes
+ *     helpers give the required sizes; workspaces may be reused by the next call on the same stream;
+ *   - entry points are stateless and re-entrant (forward on the caller's thread, backward on the autograd
+ *     worker thread, each with its own stream).
+ */
+#ifndef LOCATE_HIP_H
+#define LOCATE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* locate_last_error(void);
+int locate_abi_version(void);
+/* architecture name ("gfx950..."), compute units and wavefront size of the current device */
+int locate_device_info(char* arch_name, int name_len, int* cu_count, int* wave_size);
+
+/* ---- RootTanh: y = (x^2+1)^(1/4) tanh x and its hand-written derivative (libs/activation.py:7-36) ---- */
+int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
+/* generator output tanh (libs/models.py:66); backward takes the forward OUTPUT y */
+int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream);
+
+/* ---- InPlaceNorm: global scalar mean / unbiased std, per-channel or per-sample scale, per-channel bias
+ *      (libs/inplace_norm.py:4-45).  stats = {mean, std}. ---- */
+size_t locate_norm_stats_workspace_bytes(void);
+int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, void* stream);
+/* out = (x - mean) * scale / std + bias; scale is [C] (scale_per_sample = 0) or [B*C]; act_out (nullable)
+ * additionally receives RootTanh(out) (the conv stage that follows starts with RootTanh, libs/conv.py:22-24) */
+int locate_norm_apply_fwd(const float* x, const float* stats, const float* scale, int scale_per_sample, const float* bias,
+                          float* out, float* act_out, int B, int C, int hw, void* stream);
+size_t locate_norm_bwd_workspace_bytes(int B, int C);
+/* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward) */
+int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample, float* dx,
+                    float* dscale, float* dbias, int B, int C, int hw, void* workspace, void* stream);
+/* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
+int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream);
+
+/* ---- residual gate out = (gamma a + 1) x (libs/merge.py:19-62), incl. dgamma = sum x^2 g as coded.
+ *      a_per_plane = 1: `a` holds one value per (batch, channel) plane (stride-0 expand, libs/util_modules.py:6-12) */
+int locate_gate_fwd(const float* x, const float* a, int a_per_plane, const float* gamma, float* out, int64_t planes, int hw,
+                    void* stream);
+size_t locate_gate_bwd_workspace_bytes(int64_t planes);
+int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g, float* dx, float* da,
+                    float* dgamma, int64_t planes, int hw, void* workspace, void* stream);
+
+/* ---- softmax over the last dimension of [rows, n] (libs/attention.py:35,47) ---- */
+int locate_softmax_fwd(const float* x, float* y, int64_t rows, int n, void* stream);
+int locate_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, int n, void* stream);
+
+/* ---- skip-branch resampling / indexing (libs/scale.py:7-45, libs/merge.py:4-16) ---- */
+int locate_upsample2x_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);   /* bilinear, align_corners=False */
+int locate_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream); /* H, W: forward input size */
+int locate_avgpool2_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);
+int locate_avgpool2_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream);   /* H, W: forward input size */
+int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, int r, void* stream);         /* mean of r adjacent flat elements */
+int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, void* stream);
+/* dst[b, c, :] (+)= src[b, c, :], c < C, independent batch strides (torch.cat along channels and its backward) */
+int locate_copy_channels(const float* src, float* dst, int B, int C, int hw, int64_t src_batch_stride,
+                         int64_t dst_batch_stride, int accumulate, void* stream);
+
+/* ---- spectral norm state machine (libs/spectral_norm.py:21-32): one power iteration, u/v updated in place,
+ *      sigma = {sigma, 1/sigma}, wv = W v (kept for du).  W_bar viewed as [h, wd], h = shape[0]. ---- */
+size_t locate_sn_workspace_bytes(int h, int wd);
+int locate_sn_power_iter(const float* w, float* u, float* v, float* sigma, float* wv, int h, int wd, void* workspace,
+                         void* stream);
+/* all layers of a network in four launches; `table`: device array of records {w,u,v,sigma,wv,t,s,tpart pointers;
+ * int h, wd, nchunk, pad} (locate_sn_table_record_bytes() each), scratch t[wd], s[h], tpart[ceil(h/64)*wd] */
+size_t locate_sn_table_record_bytes(void);
+int locate_sn_power_iter_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream);
+/* dW_bar = g/sigma + dsigma u v^T, du = dsigma (W v), dv = dsigma W^T u with dsigma = -<g, W_bar>/sigma^2;
+ * u, v are the CURRENT state (the reference's autograd sees the latest .data); du, dv nullable */
+size_t locate_sn_bwd_workspace_bytes(int h, int wd);
+int locate_sn_weight_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma, const float* wv,
+                         float* dw, float* du, float* dv, int h, int wd, void* workspace, void* stream);
+
+/* ---- dense contractions as implicit GEMMs on the fp32 MFMA (libs/conv.py:14-20, libs/attention.py:18-46,
+ *      libs/scale.py:25-34, libs/linear.py:10).  geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW}
+ *      describes the REGULAR convolution R: out[b,m,oh,ow] = sum w[m,c,kh,kw] in[b,c,oh*s-ph+kh,ow*s-pw+kw].
+ *      inv_scale (nullable device scalar) multiplies the weights (1/sigma of spectral norm);
+ *      *_bs are batch strides in elements. ---- */
+size_t locate_conv_fwd_workspace_bytes(const int* geom);
+int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale, const float* bias,
+                    float* y, int64_t y_bs, void* workspace, void* stream);
+/* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]) */
+size_t locate_conv_dgrad_workspace_bytes(const int* geom);
+int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale, const float* bias,
+                      float* gx, int64_t gx_bs, void* workspace, void* stream);
+/* gw[m,c,kh,kw] = sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction) */
+size_t locate_conv_wgrad_workspace_bytes(const int* geom);
+int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
+                      void* workspace, void* stream);
+
+/* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
+size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */
+int locate_nadam_chunk_elems(void);
+int locate_nadam_step(const void* tensors, void* coef, const void* chunks, int n_tensors, int n_chunks, double lr, double beta1,
+                      double beta2, double eps, double schedule_decay, void* stream);
+
+/* ---- loss glue (main.py:149-156,164-169, libs/utils.py:133-134, libs/grad_penalty.py:1-2): values and the
+ *      gradients w.r.t. the discriminator outputs ---- */
+int locate_d_loss(const float* d_true, const float* d_fake, const float* d_aug, int B, float gamma, float* losses,
+                  float* g_true, float* g_fake, float* g_aug, void* stream);
+int locate_g_loss(const float* d_fake, int B, float* loss, float* g_fake, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

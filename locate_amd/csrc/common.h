@@ -1,0 +1,111 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the LocAtE hot path.
+// Wave = 64 lanes; every block size in this library is a multiple of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define LOCATE_OK 0
+#define LOCATE_ERR_ARG 1
+#define LOCATE_ERR_LAUNCH 2
+
+#define LOCATE_API extern "C" __attribute__((visibility("default")))
+
+void locate_set_error(const char* fmt, ...);
+
+#define LOCATE_REQUIRE(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            locate_set_error(__VA_ARGS__);        \
+            return LOCATE_ERR_ARG;                \
+        }                                         \
+    } while (0)
+
+#define LOCATE_LAUNCH_CHECK(name)                                                   \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            locate_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return LOCATE_ERR_LAUNCH;                                               \
+        }                                                                           \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+static inline int stream_grid(int64_t work_items, int per_block) {
+    int64_t g = cdiv64(work_items, per_block);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (a multiple of 64). `scratch` holds >= 16 values.
+// Every thread returns the total.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    T t = 0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t = scratch[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+// RootTanh pieces shared by the element-wise kernels and the fused norm/conv epilogues (see elementwise.hip).
+__device__ __forceinline__ void tanh_sech2(float x, float& th, float& sech2) {
+    const float ax = fabsf(x);
+    const float em = expm1f(-2.0f * ax);
+    const float d = 2.0f + em;
+    const float r = 1.0f / d;
+    th = copysignf(-em * r, x);
+    sech2 = 4.0f * (1.0f + em) * r * r;
+}
+
+__device__ __forceinline__ float roottanh_f(float x) {
+    float th, s2;
+    tanh_sech2(x, th, s2);
+    return sqrtf(sqrtf(fmaf(x, x, 1.0f))) * th;
+}
+
+__device__ __forceinline__ float roottanh_grad_f(float x, float g) {
+    float th, s2;
+    tanh_sech2(x, th, s2);
+    const float q = fmaf(x, x, 1.0f);
+    const float r = sqrtf(sqrtf(q));          // q^(1/4)
+    const float q34 = r * r * r;              // q^(3/4)
+    return g * (2.0f * q * s2 + x * th) / (2.0f * q34);
+}
+
+#endif

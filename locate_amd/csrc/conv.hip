@@ -1,0 +1,593 @@
+// Dense contractions of the LocAtE hot path as LDS-tiled implicit GEMMs on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s dense peak on MI355X).  No im2col buffer is ever
+// materialised: the activation operand is gathered straight from NCHW into LDS.
+//
+// Everything is expressed through ONE regular convolution R
+//     out[b, m, oh, ow] = sum_{c, kh, kw} w[m, c, kh, kw] * in[b, c, oh*s - ph + kh, ow*s - pw + kw]
+// and its two adjoints:
+//     locate_conv_fwd    R            Conv2d / Conv1d(k=1) / Linear forward  (reference libs/conv.py:14-20,
+//                                     attention.py:18-46, scale.py:25-34, linear.py:10); ConvTranspose2d dgrad
+//     locate_conv_dgrad  R^T (data)   Conv2d dgrad; ConvTranspose2d FORWARD (conv.py:49-52: both convs of a
+//                                     transposed stage are ConvTranspose2d, weights [C_in, C_out, k, k])
+//     locate_conv_wgrad  R^T (weight) weight gradient of either (roles of the two activations swapped by the
+//                                     caller for the transposed case)
+// A stride-s adjoint is decomposed into s*s sub-pixel phases, each a stride-1 gather with its own tap subset
+// (4x4 s2 p1 ConvTranspose = four 2x2 convolutions; 5x5 s2 p2 dgrad = 3x3 + 3x2 + 2x3 + 2x2 taps).
+//
+// The weight operand is re-packed per call into a K-major [Kpad][Mpad] panel (zero padded) with the
+// spectral-norm factor 1/sigma folded in (reference libs/spectral_norm.py:31-32 materialises W_bar/sigma
+// as a separate full-size tensor on every forward; here it only ever exists as the packed panel).
+//
+// Tiling: 256 threads = 4 waves, block tile BM x 128 (BM in {128, 96, 64, 32}), K step 16, double-buffered
+// LDS with register prefetch of the next K step, one barrier per step.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define IG_BK 16
+#define IG_MAXT 32
+
+struct ConvGeom {
+    int B, C, H, W;            // input of R
+    int M, KH, KW;             // weight [M, C, KH, KW]
+    int stride, pad_h, pad_w;
+    int OH, OW;                // output of R
+};
+
+static int geom_check(const ConvGeom& g, const char* who) {
+    LOCATE_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0 && g.M > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0,
+                   "%s: non-positive dimension", who);
+    LOCATE_REQUIRE(g.KH * g.KW <= IG_MAXT - 7, "%s: kernel %dx%d has more than %d taps", who, g.KH, g.KW, IG_MAXT - 7);
+    LOCATE_REQUIRE(g.stride <= 2, "%s: stride %d unsupported (1 or 2)", who, g.stride);
+    LOCATE_REQUIRE(g.OH == (g.H + 2 * g.pad_h - g.KH) / g.stride + 1 && g.OW == (g.W + 2 * g.pad_w - g.KW) / g.stride + 1,
+                   "%s: output size %dx%d does not match the geometry", who, g.OH, g.OW);
+    LOCATE_REQUIRE((int64_t)g.B * g.C * g.H * g.W < (1ll << 31) && (int64_t)g.B * g.M * g.OH * g.OW < (1ll << 31),
+                   "%s: tensor larger than 2^31 elements", who);
+    return LOCATE_OK;
+}
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w;       // [M, C, KH, KW]
+    const float* inv_scale;  // device scalar or null
+    float* out;           // [Kpad][ld]
+    int M, C, KH, KW;
+    int mode;             // 0: rows k=(c,kh,kw), cols m          (R forward)
+                          // 1: rows k=(m,th,tw), cols c, taps kh = kh0 + s*th, kw = kw0 + s*tw   (R data-adjoint phase)
+    int kh0, kw0, s, TH, TW;
+    int K, Kpad, ld;
+};
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
+    const float sc = a.inv_scale ? a.inv_scale[0] : 1.0f;
+    const int64_t total = (int64_t)a.Kpad * a.ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int k = (int)(i / a.ld), col = (int)(i - (int64_t)k * a.ld);
+        float v = 0.0f;
+        if (k < a.K) {
+            if (a.mode == 0) {
+                if (col < a.M) {
+                    const int taps = a.KH * a.KW;
+                    const int c = k / taps, t = k - c * taps;
+                    v = a.w[((int64_t)col * a.C + c) * taps + t] * sc;
+                }
+            } else {
+                if (col < a.C) {
+                    const int tt = a.TH * a.TW;
+                    const int m = k / tt, r = k - m * tt;
+                    const int th = r / a.TW, tw = r - th * a.TW;
+                    const int kh = a.kh0 + a.s * th, kw = a.kw0 + a.s * tw;
+                    v = a.w[(((int64_t)m * a.C + col) * a.KH + kh) * a.KW + kw] * sc;
+                }
+            }
+        }
+        a.out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM gather kernel:  out[b, m, oy, ox] = sum_{c, t} wp[(c*T + t)][m] * in[b, c, qy*istride + dy[t], qx*istride + dx[t]]
+//   with (oy, ox) = (oy0 + qy*ostep, ox0 + qx*ostep), zero outside the input.
+// ---------------------------------------------------------------------------------------------
+struct IgPhase {
+    const float* wp;   // packed weights [Kpad][ld]
+    int K, Kpad, ld, T;
+    int oy0, ox0, QH, QW;
+    signed char dy[IG_MAXT], dx[IG_MAXT];
+};
+
+struct IgParams {
+    const float* in;
+    float* out;
+    const float* bias;   // [M] or null
+    long long in_bs, out_bs;
+    int B, C, H, W;      // gathered tensor: C = reduction channels
+    int M, OH, OW;       // produced tensor
+    int istride, ostep, nphase;
+    IgPhase ph[4];
+};
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
+    constexpr int BM = WGM * TM * 32;
+    constexpr int BN = WGN * TN * 32;
+    constexpr int KPT = IG_BK * BN / 256;             // gathered elements per thread per K step
+    constexpr int A_F4 = IG_BK * BM / 4;              // float4 per A tile
+    constexpr int A_PT = (A_F4 + 255) / 256;
+    static_assert(WGM * WGN == 4, "four waves");
+    static_assert(BN % 64 == 0 && KPT >= 1, "column groups must be wave-aligned");
+
+    __shared__ __attribute__((aligned(16))) float As[2][IG_BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][IG_BK][BN];
+    __shared__ int doff_s[IG_MAXT];
+
+    const IgPhase& ph = p.ph[blockIdx.z];
+    const int N = p.B * ph.QH * ph.QW;
+    const int n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    if (n0 >= N) return;   // phases can have different extents; uniform per block
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int HW = p.H * p.W;
+    const int T = ph.T;
+
+    if (tid < IG_MAXT) doff_s[tid] = tid < T ? (int)ph.dy[tid] * p.W + (int)ph.dx[tid] : 0;
+
+    // ---- per-thread gather column (fixed for the whole K loop)
+    const int ncol = tid % BN;
+    const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform
+    const int n = n0 + ncol;
+    const bool n_ok = n < N;
+    unsigned tapmask = 0;
+    const float* in_col = p.in;
+    {
+        const int nn = n_ok ? n : 0;
+        const int qhw = ph.QH * ph.QW;
+        const int b = nn / qhw, q = nn - b * qhw;
+        const int qy = q / ph.QW, qx = q - qy * ph.QW;
+        const int iy0 = qy * p.istride, ix0 = qx * p.istride;
+        in_col += (long long)b * p.in_bs + (long long)iy0 * p.W + ix0;
+        if (n_ok) {
+            for (int t = 0; t < T; ++t) {
+                const bool ok = (unsigned)(iy0 + ph.dy[t]) < (unsigned)p.H && (unsigned)(ix0 + ph.dx[t]) < (unsigned)p.W;
+                tapmask |= (ok ? 1u : 0u) << t;
+            }
+        }
+    }
+    __syncthreads();   // doff_s ready
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float breg[KPT];
+    float4 areg[A_PT];
+
+    auto load_tiles = [&](int k0) {
+        // weights: K-major panel, rows always exist (Kpad), columns guarded by ld
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int idx = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < A_F4) {
+                const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
+                const int col = m0 + c4 * 4;
+                if (col < ph.ld) v = *reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + col);
+            }
+            areg[i] = v;
+        }
+        // activations: (c, t) is wave-uniform
+        int kk = k0 + kgrp * KPT;
+        int c = kk / T, t = kk - c * T;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            float v = 0.0f;
+            if (kk < ph.K && ((tapmask >> t) & 1u)) v = in_col[(long long)c * HW + doff_s[t]];
+            breg[j] = v;
+            ++kk; ++t;
+            if (t == T) { t = 0; ++c; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < A_F4) {
+                const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
+                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = breg[j];
+    };
+
+    const int nsteps = ph.Kpad / IG_BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int lrow = lane >> 5, lcol = lane & 31;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_tiles((s + 1) * IG_BK);
+#pragma unroll
+        for (int k2 = 0; k2 < IG_BK / 2; ++k2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][k2 * 2 + lrow][(wm * TM + i) * 32 + lcol];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][k2 * 2 + lrow][(wn * TN + j) * 32 + lcol];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const long long plane = (long long)p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nj = n0 + (wn * TN + j) * 32 + lcol;
+        if (nj >= N) continue;
+        const int qhw = ph.QH * ph.QW;
+        const int b = nj / qhw, q = nj - b * qhw;
+        const int qy = q / ph.QW, qx = q - qy * ph.QW;
+        float* optr = p.out + (long long)b * p.out_bs + (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[m];
+                    optr[(long long)m * plane] = v;
+                }
+            }
+        }
+    }
+}
+
+static int pick_bm(int M) {
+    const int cands[4] = {128, 96, 64, 32};
+    int best = 128, best_pad = 1 << 30;
+    for (int i = 0; i < 4; ++i) {
+        const int pad = round_up(M, cands[i]);
+        if (pad < best_pad) { best_pad = pad; best = cands[i]; }
+    }
+    return best;
+}
+
+static int launch_igemm(const IgParams& p, int nmax, hipStream_t st, const char* who) {
+    const int bm = pick_bm(p.M);
+    dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase);
+    if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+    else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+    else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+    else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    LOCATE_LAUNCH_CHECK(who);
+    return LOCATE_OK;
+}
+
+static int launch_pack(const PackArgs& a, hipStream_t st, const char* who) {
+    pack_weights_kernel<<<stream_grid((int64_t)a.Kpad * a.ld, 256), 256, 0, st>>>(a);
+    LOCATE_LAUNCH_CHECK(who);
+    return LOCATE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static ConvGeom make_geom(const int* g) {
+    ConvGeom c;
+    c.B = g[0]; c.C = g[1]; c.H = g[2]; c.W = g[3]; c.M = g[4]; c.KH = g[5]; c.KW = g[6];
+    c.stride = g[7]; c.pad_h = g[8]; c.pad_w = g[9]; c.OH = g[10]; c.OW = g[11];
+    return c;
+}
+
+// geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
+LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) {
+    const ConvGeom g = make_geom(geom);
+    return (size_t)round_up(g.C * g.KH * g.KW, IG_BK) * round_up(g.M, 32) * sizeof(float);
+}
+
+// y[b, m, oh, ow] = bias[m] + inv_scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]
+// x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
+LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
+                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_fwd")) return e;
+    LOCATE_REQUIRE(workspace && x && w && y, "locate_conv_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    PackArgs pa;
+    pa.w = w; pa.inv_scale = inv_scale; pa.out = static_cast<float*>(workspace);
+    pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
+    pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
+    pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_BK); pa.ld = round_up(g.M, 32);
+    if (int e = launch_pack(pa, st, "locate_conv_fwd(pack)")) return e;
+
+    IgParams p;
+    p.in = x; p.out = y; p.bias = bias; p.in_bs = x_bs; p.out_bs = y_bs;
+    p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW;
+    p.istride = g.stride; p.ostep = 1; p.nphase = 1;
+    IgPhase& ph = p.ph[0];
+    ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
+    ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
+    for (int kh = 0; kh < g.KH; ++kh)
+        for (int kw = 0; kw < g.KW; ++kw) {
+            ph.dy[kh * g.KW + kw] = (signed char)(kh - g.pad_h);
+            ph.dx[kh * g.KW + kw] = (signed char)(kw - g.pad_w);
+        }
+    return launch_igemm(p, g.B * g.OH * g.OW, st, "locate_conv_fwd(igemm)");
+}
+
+static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int* T) {
+    *k0 = (parity + pad) % s;
+    *d0 = (parity + pad - *k0) / s;
+    *T = *k0 < K ? (K - *k0 + s - 1) / s : 0;
+}
+
+LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) {
+    const ConvGeom g = make_geom(geom);
+    size_t total = 0;
+    for (int py = 0; py < g.stride; ++py)
+        for (int px = 0; px < g.stride; ++px) {
+            int kh0, dy0, TH, kw0, dx0, TW;
+            phase_taps(py, g.pad_h, g.KH, g.stride, &kh0, &dy0, &TH);
+            phase_taps(px, g.pad_w, g.KW, g.stride, &kw0, &dx0, &TW);
+            total += (size_t)round_up(g.M * TH * TW, IG_BK) * round_up(g.C, 32);
+        }
+    return total * sizeof(float);
+}
+
+// gx[b, c, i, j] = bias[c] + inv_scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
+// (data adjoint of R; it is also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]).
+// Every element of gx [B, C, H, W] is written.
+LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
+                                 const float* bias, float* gx, int64_t gx_bs, void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_dgrad")) return e;
+    LOCATE_REQUIRE(workspace && gy && w && gx, "locate_conv_dgrad: null pointer");
+    hipStream_t st = as_stream(stream);
+    IgParams p;
+    p.in = gy; p.out = gx; p.bias = bias; p.in_bs = gy_bs; p.out_bs = gx_bs;
+    p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
+    p.istride = 1; p.ostep = g.stride; p.nphase = 0;
+    float* wsp = static_cast<float*>(workspace);
+    int nmax = 0;
+    for (int py = 0; py < g.stride; ++py)
+        for (int px = 0; px < g.stride; ++px) {
+            int kh0, dy0, TH, kw0, dx0, TW;
+            phase_taps(py, g.pad_h, g.KH, g.stride, &kh0, &dy0, &TH);
+            phase_taps(px, g.pad_w, g.KW, g.stride, &kw0, &dx0, &TW);
+            const int QH = py < g.H ? (g.H - py + g.stride - 1) / g.stride : 0;
+            const int QW = px < g.W ? (g.W - px + g.stride - 1) / g.stride : 0;
+            if (QH == 0 || QW == 0) continue;
+            IgPhase& ph = p.ph[p.nphase++];
+            PackArgs pa;
+            pa.w = w; pa.inv_scale = inv_scale; pa.out = wsp;
+            pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
+            pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
+            pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_BK); pa.ld = round_up(g.C, 32);
+            if (int e = launch_pack(pa, st, "locate_conv_dgrad(pack)")) return e;
+            wsp += (size_t)pa.Kpad * pa.ld;
+            ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
+            ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
+            for (int th = 0; th < TH; ++th)
+                for (int tw = 0; tw < TW; ++tw) {
+                    ph.dy[th * TW + tw] = (signed char)(dy0 - th);
+                    ph.dx[th * TW + tw] = (signed char)(dx0 - tw);
+                }
+            const int nph = g.B * QH * QW;
+            if (nph > nmax) nmax = nph;
+        }
+    LOCATE_REQUIRE(p.nphase > 0, "locate_conv_dgrad: empty output");
+    return launch_igemm(p, nmax, st, "locate_conv_dgrad(igemm)");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  gw[m, c, kh, kw] = sum_{b, oh, ow} gy[b, m, oh, ow] * x[b, c, oh*s-ph+kh, ow*s-pw+kw]
+// GEMM rows = m, columns r = (c, kh, kw), reduction over n = (b, oh, ow) split over blockIdx.z into slabs
+// (deterministic: slabs are summed in a fixed order by a second kernel).
+// ---------------------------------------------------------------------------------------------
+#define WG_BK 32
+
+struct WgParams {
+    const float* x;     // gathered activation [B, C, H, W]
+    const float* gy;    // dense activation    [B, M, OH, OW]
+    float* slab;        // [nsplit][M * R]
+    long long x_bs, gy_bs;
+    int B, C, H, W, M, OH, OW, KH, KW, stride, pad_h, pad_w;
+    int R;              // C * KH * KW
+    int N;              // B * OH * OW
+    int chunk;          // reduction elements per split (multiple of WG_BK)
+};
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
+    constexpr int BM = WGM * TM * 32;
+    constexpr int BR = WGN * TN * 32;
+    constexpr int G_PT = WG_BK * BM / 256;
+    constexpr int X_PT = WG_BK * BR / 256;
+    static_assert(WGM * WGN == 4, "four waves");
+
+    __shared__ float Gs[2][WG_BK][BM + 1];
+    __shared__ float Xs[2][WG_BK][BR + 1];
+    __shared__ int rt_off[BR];       // c*H*W + dy*W + dx, or INT_MIN for r >= R
+    __shared__ signed char rt_dy[BR], rt_dx[BR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int r0 = blockIdx.x * BR, m0 = blockIdx.y * BM;
+    const int taps = p.KH * p.KW;
+    for (int i = tid; i < BR; i += 256) {
+        const int r = r0 + i;
+        if (r < p.R) {
+            const int c = r / taps, t = r - c * taps;
+            const int kh = t / p.KW, kw = t - kh * p.KW;
+            rt_dy[i] = (signed char)(kh - p.pad_h);
+            rt_dx[i] = (signed char)(kw - p.pad_w);
+            rt_off[i] = c * p.H * p.W + (kh - p.pad_h) * p.W + (kw - p.pad_w);
+        } else {
+            rt_dy[i] = rt_dx[i] = 0;
+            rt_off[i] = -2147483647 - 1;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_begin = blockIdx.z * p.chunk;
+    int n_end = n_begin + p.chunk;
+    if (n_end > p.N) n_end = p.N;
+    const int nl = tid & 31, sub = tid >> 5;   // reduction lane, row/column subgroup (0..7)
+    const int Q = p.OH * p.OW;
+
+    float greg[G_PT], xreg[X_PT];
+    auto load_tiles = [&](int nb) {
+        const int n = nb + nl;
+        const bool ok = n < n_end;
+        const int nn = ok ? n : 0;
+        const int b = nn / Q, q = nn - b * Q;
+        const int oh = q / p.OW, ow = q - oh * p.OW;
+        const float* gp = p.gy + (long long)b * p.gy_bs + q;
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int m = m0 + sub + 8 * i;
+            greg[i] = (ok && m < p.M) ? gp[(long long)m * Q] : 0.0f;
+        }
+        const int iy0 = oh * p.stride, ix0 = ow * p.stride;
+        const float* xp = p.x + (long long)b * p.x_bs + (long long)iy0 * p.W + ix0;
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) {
+            const int rl = sub + 8 * i;
+            const int off = rt_off[rl];
+            const bool v = ok && off != (-2147483647 - 1) && (unsigned)(iy0 + rt_dy[rl]) < (unsigned)p.H &&
+                           (unsigned)(ix0 + rt_dx[rl]) < (unsigned)p.W;
+            xreg[i] = v ? xp[off] : 0.0f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) Gs[buf][nl][sub + 8 * i] = greg[i];
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) Xs[buf][nl][sub + 8 * i] = xreg[i];
+    };
+
+    const int nsteps = (n_end - n_begin + WG_BK - 1) / WG_BK;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    if (nsteps > 0) {
+        load_tiles(n_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_tiles(n_begin + (s + 1) * WG_BK);
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Gs[buf][k2 * 2 + lrow][(wm * TM + i) * 32 + lcol];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[buf][k2 * 2 + lrow][(wn * TN + j) * 32 + lcol];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* slab = p.slab + (long long)blockIdx.z * p.M * p.R;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = r0 + (wn * TN + j) * 32 + lcol;
+        if (r >= p.R) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
+                if (m < p.M) slab[(long long)m * p.R + r] = acc[i][j][e];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
+                                                          int nsplit) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float acc = 0.0f;
+        for (int z = 0; z < nsplit; ++z) acc += slab[(int64_t)z * n + i];
+        out[i] = acc;
+    }
+}
+
+static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk) {
+    *bm = pick_bm(g.M);
+    const int R = g.C * g.KH * g.KW;
+    const int64_t N = (int64_t)g.B * g.OH * g.OW;
+    const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
+    int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks (256 CUs x 4)
+    const int64_t max_split = (N + 255) / 256;           // at least 256 reduction elements per block
+    if (want > max_split) want = max_split;
+    if (want > 512) want = 512;
+    if (want < 1) want = 1;
+    int64_t ch = (N + want - 1) / want;
+    ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
+    *chunk = (int)ch;
+    *nsplit = (int)((N + ch - 1) / ch);
+}
+
+LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
+    const ConvGeom g = make_geom(geom);
+    int bm, nsplit, chunk;
+    wgrad_plan(g, &bm, &nsplit, &chunk);
+    return (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float);
+}
+
+// gw: [M, C, KH, KW], overwritten.
+LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
+                                 void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_wgrad")) return e;
+    LOCATE_REQUIRE(workspace && x && gy && gw, "locate_conv_wgrad: null pointer");
+    hipStream_t st = as_stream(stream);
+    int bm, nsplit, chunk;
+    wgrad_plan(g, &bm, &nsplit, &chunk);
+    WgParams p;
+    p.x = x; p.gy = gy; p.slab = static_cast<float*>(workspace); p.x_bs = x_bs; p.gy_bs = gy_bs;
+    p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW; p.KH = g.KH; p.KW = g.KW;
+    p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+    p.R = g.C * g.KH * g.KW; p.N = g.B * g.OH * g.OW; p.chunk = chunk;
+    dim3 grid((p.R + 127) / 128, (g.M + bm - 1) / bm, nsplit);
+    if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+    else if (bm == 96) conv_wgrad_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+    else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    LOCATE_LAUNCH_CHECK("locate_conv_wgrad(gemm)");
+    const int64_t n = (int64_t)g.M * p.R;
+    slab_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>(p.slab, gw, n, nsplit);
+    LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
+    return LOCATE_OK;
+}

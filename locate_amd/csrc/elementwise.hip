@@ -1,0 +1,226 @@
+// Element-wise kernels of the LocAtE hot path (all HBM-bound, 16 B per lane, grid-strided):
+//   RootTanh fwd/bwd        reference libs/activation.py:7-36
+//   tanh fwd/bwd            reference libs/models.py:66 (generator output)
+//   residual gate fwd/bwd   reference libs/merge.py:19-39 (incl. the x^2 gamma-gradient as coded)
+//   channel-slice copy      reference libs/merge.py:15 (torch.cat along channels) and its backward
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// RootTanh:  y = (x^2+1)^(1/4) * tanh(x)
+//   dy/dx = [2 (x^2+1) sech^2(x) + x tanh(x)] / (2 (x^2+1)^(3/4))          (ROOTTANH_GROWTH = 4)
+// tanh and sech^2 come from one expm1: em = expm1(-2|x|) in (-1, 0]:
+//   tanh|x| = -em / (2 + em),  sech^2 x = 4 (1 + em) / (2 + em)^2
+// which is accurate for tiny |x| and saturates cleanly (sech^2 -> 0, tanh -> 1) for large |x|, where the
+// reference's 1/cosh^2 overflows to 1/inf = 0 (activation.py:24-26) - same limit, finite result.
+// ---------------------------------------------------------------------------------------------
+template <int OP>  // 0 roottanh, 1 tanh
+__global__ void __launch_bounds__(256) unary_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i], o;
+        if (OP == 0) {
+            o.x = roottanh_f(v.x); o.y = roottanh_f(v.y); o.z = roottanh_f(v.z); o.w = roottanh_f(v.w);
+        } else {
+            o.x = tanhf(v.x); o.y = tanhf(v.y); o.z = tanhf(v.z); o.w = tanhf(v.w);
+        }
+        y4[i] = o;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = OP == 0 ? roottanh_f(x[i]) : tanhf(x[i]);
+}
+
+// OP 0: gx = g * roottanh'(a) with a = forward INPUT.   OP 1: gx = g * (1 - a^2) with a = forward OUTPUT.
+template <int OP>
+__global__ void __launch_bounds__(256) unary_bwd_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                                                        float* __restrict__ gx, int64_t n) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* o4 = reinterpret_cast<float4*>(gx);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = a4[i], w = g4[i], o;
+        if (OP == 0) {
+            o.x = roottanh_grad_f(v.x, w.x); o.y = roottanh_grad_f(v.y, w.y);
+            o.z = roottanh_grad_f(v.z, w.z); o.w = roottanh_grad_f(v.w, w.w);
+        } else {
+            o.x = w.x * (1.0f - v.x * v.x); o.y = w.y * (1.0f - v.y * v.y);
+            o.z = w.z * (1.0f - v.z * v.z); o.w = w.w * (1.0f - v.w * v.w);
+        }
+        o4[i] = o;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        gx[i] = OP == 0 ? roottanh_grad_f(a[i], g[i]) : g[i] * (1.0f - a[i] * a[i]);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+LOCATE_API int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+    LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_roottanh_fwd: bad size or unaligned pointer");
+    if (n == 0) return LOCATE_OK;
+    unary_fwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n);
+    LOCATE_LAUNCH_CHECK("locate_roottanh_fwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream) {
+    LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(gy) && aligned16(gx), "locate_roottanh_bwd: bad size or unaligned pointer");
+    if (n == 0) return LOCATE_OK;
+    unary_bwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, gy, gx, n);
+    LOCATE_LAUNCH_CHECK("locate_roottanh_bwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+    LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_tanh_fwd: bad size or unaligned pointer");
+    if (n == 0) return LOCATE_OK;
+    unary_fwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n);
+    LOCATE_LAUNCH_CHECK("locate_tanh_fwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream) {
+    LOCATE_REQUIRE(n >= 0 && aligned16(y) && aligned16(gy) && aligned16(gx), "locate_tanh_bwd: bad size or unaligned pointer");
+    if (n == 0) return LOCATE_OK;
+    unary_bwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(y, gy, gx, n);
+    LOCATE_LAUNCH_CHECK("locate_tanh_bwd");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Residual gate: out = (gamma * a + 1) * x     (merge.py:21-28)
+//   a is either a full [planes, hw] tensor (a_per_plane = 0) or one value per (batch, channel) plane
+//   (a_per_plane = 1: feature attention's [B, C, 1, 1] expanded with stride 0, util_modules.py:6-12).
+//   gamma is a device scalar (the [1,1] Parameter).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                       const float* __restrict__ gamma, float* __restrict__ out,
+                                                       int64_t n, int hw, int a_per_plane) {
+    const float gm = gamma[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (!a_per_plane && (n & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+            float4 xv = x4[i], av = a4[i], o;
+            o.x = fmaf(gm, av.x, 1.0f) * xv.x; o.y = fmaf(gm, av.y, 1.0f) * xv.y;
+            o.z = fmaf(gm, av.z, 1.0f) * xv.z; o.w = fmaf(gm, av.w, 1.0f) * xv.w;
+            o4[i] = o;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float av = a_per_plane ? a[i / hw] : a[i];
+        out[i] = fmaf(gm, av, 1.0f) * x[i];
+    }
+}
+
+// One wave per plane: dx, da (full) and the per-plane sums  sum x*g  and  sum x^2*g.
+__global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                             const float* __restrict__ gamma, const float* __restrict__ g,
+                                                             float* __restrict__ dx, float* __restrict__ da_full,
+                                                             float* __restrict__ plane_xg, float* __restrict__ plane_x2g,
+                                                             int64_t planes, int hw, int a_per_plane) {
+    const float gm = gamma[0];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = wave; p < planes; p += nwaves) {
+        const int64_t base = p * hw;
+        const float ap = a_per_plane ? a[p] : 0.0f;
+        float sxg = 0.0f, sx2g = 0.0f;
+        for (int i = lane; i < hw; i += 64) {
+            const float xv = x[base + i], gv = g[base + i];
+            const float av = a_per_plane ? ap : a[base + i];
+            const float xg = xv * gv;
+            dx[base + i] = fmaf(gm, av, 1.0f) * gv;
+            if (!a_per_plane) da_full[base + i] = xg * gm;
+            sxg += xg;
+            sx2g = fmaf(xg, xv, sx2g);
+        }
+        sxg = wave_sum(sxg);
+        sx2g = wave_sum(sx2g);
+        if (lane == 0) {
+            plane_xg[p] = sxg;
+            plane_x2g[p] = sx2g;
+        }
+    }
+}
+
+// dgamma = sum_p plane_x2g[p] (reference bug: x^2 g, merge.py:33-38);  da[p] = gamma * plane_xg[p] (broadcast mode)
+__global__ void __launch_bounds__(1024) gate_bwd_final_kernel(const float* __restrict__ plane_xg,
+                                                              const float* __restrict__ plane_x2g,
+                                                              const float* __restrict__ gamma, float* __restrict__ da_plane,
+                                                              float* __restrict__ dgamma, int64_t planes, int a_per_plane) {
+    __shared__ double scratch[16];
+    const float gm = gamma[0];
+    double acc = 0.0;
+    for (int64_t p = threadIdx.x; p < planes; p += blockDim.x) {
+        acc += (double)plane_x2g[p];
+        if (a_per_plane) da_plane[p] = gm * plane_xg[p];
+    }
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) dgamma[0] = (float)acc;
+}
+
+LOCATE_API int locate_gate_fwd(const float* x, const float* a, int a_per_plane, const float* gamma, float* out,
+                               int64_t planes, int hw, void* stream) {
+    LOCATE_REQUIRE(planes >= 0 && hw > 0, "locate_gate_fwd: bad shape");
+    const int64_t n = planes * hw;
+    if (n == 0) return LOCATE_OK;
+    gate_fwd_kernel<<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, a, gamma, out, n, hw, a_per_plane);
+    LOCATE_LAUNCH_CHECK("locate_gate_fwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { return (size_t)planes * 2 * sizeof(float); }
+
+// da: [planes*hw] when a_per_plane == 0, [planes] otherwise.  dgamma: one float (overwritten).
+LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g,
+                               float* dx, float* da, float* dgamma, int64_t planes, int hw, void* workspace,
+                               void* stream) {
+    LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
+    float* plane_xg = static_cast<float*>(workspace);
+    float* plane_x2g = plane_xg + planes;
+    int64_t blocks = cdiv64(planes, 4);
+    if (blocks > 4096) blocks = 4096;
+    gate_bwd_plane_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
+                                                                     plane_xg, plane_x2g, planes, hw, a_per_plane);
+    LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
+    gate_bwd_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(plane_xg, plane_x2g, gamma, a_per_plane ? da : nullptr,
+                                                            dgamma, planes, a_per_plane);
+    LOCATE_LAUNCH_CHECK("locate_gate_bwd(final)");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel-slice copy: dst[b, c, :] = src[b, c, :] for c < C with independent batch strides (elements).
+// Used for torch.cat([x, layer(x)], dim=1) (merge.py:15) and for slicing its gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                          int64_t chw, int64_t src_bs, int64_t dst_bs, int accumulate) {
+    const int64_t total = (int64_t)B * chw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / chw, r = i - b * chw;
+        const float v = src[b * src_bs + r];
+        float* d = dst + b * dst_bs + r;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+LOCATE_API int locate_copy_channels(const float* src, float* dst, int B, int C, int hw, int64_t src_batch_stride,
+                                    int64_t dst_batch_stride, int accumulate, void* stream) {
+    LOCATE_REQUIRE(B >= 0 && C >= 0 && hw >= 0, "locate_copy_channels: bad shape");
+    const int64_t chw = (int64_t)C * hw;
+    if ((int64_t)B * chw == 0) return LOCATE_OK;
+    LOCATE_REQUIRE(src_batch_stride >= chw && dst_batch_stride >= chw, "locate_copy_channels: batch stride smaller than slice");
+    copy_planes_kernel<<<stream_grid((int64_t)B * chw, 256), 256, 0, as_stream(stream)>>>(src, dst, B, chw, src_batch_stride,
+                                                                                         dst_batch_stride, accumulate);
+    LOCATE_LAUNCH_CHECK("locate_copy_channels");
+    return LOCATE_OK;
+}

@@ -1,0 +1,291 @@
+// InPlaceNorm (reference libs/inplace_norm.py:4-45): GLOBAL scalar mean and unbiased std over the whole
+// [B, C, H, W] tensor (no per-channel statistics, no eps, no running stats), then a per-channel weight
+// [1,C,1,1] or a per-sample style scale [B,C,1,1], plus a per-channel bias:
+//     out = (x - mu) * y / s + b
+// Backward (closed form of the reference's MeanSubMulDivAdd.backward + ATen std backward):
+//     dx = y g / s - mean(y g / s) + dz (x - mu) / ((N-1) s),   dz = -sum((x-mu) g y) / s^2
+//     dy = sum_bcast (x - mu) g / s,    db = sum_bcast g
+// All HBM-bound.  Statistics are accumulated in fp64 (the fp64 VALU rate is far above what an
+// 8 TB/s stream needs) so the result does not depend on the grid shape.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// statistics: partial (sum, sum of squares) per block in double, then one finalising block
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stats_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                            double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    double s = 0.0, q = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = x4[i];
+        const double a = v.x, b = v.y, c = v.z, d = v.w;
+        s += (a + b) + (c + d);
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double a = x[i];
+        s += a;
+        q += a * a;
+    }
+    s = block_sum<double>(s, scratch);
+    q = block_sum<double>(q, scratch);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = q;
+    }
+}
+
+// stats[0] = mean, stats[1] = unbiased std (torch.Tensor.std default), both fp32
+__global__ void __launch_bounds__(1024) stats_final_kernel(const double* __restrict__ partial, int nblocks, int64_t n,
+                                                           float* __restrict__ stats) {
+    __shared__ double scratch[16];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        s += partial[2 * i];
+        q += partial[2 * i + 1];
+    }
+    s = block_sum<double>(s, scratch);
+    q = block_sum<double>(q, scratch);
+    if (threadIdx.x == 0) {
+        const double mean = s / (double)n;
+        double var = (q - s * mean) / (double)(n - 1);
+        if (var < 0.0) var = 0.0;
+        stats[0] = (float)mean;
+        stats[1] = (float)sqrt(var);
+    }
+}
+
+LOCATE_API size_t locate_norm_stats_workspace_bytes(void) { return 2048 * 2 * sizeof(double); }
+
+LOCATE_API int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, void* stream) {
+    LOCATE_REQUIRE(n > 0 && workspace && stats, "locate_norm_stats: empty input or missing buffers");
+    LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_stats: x must be 16-byte aligned");
+    const int grid = stream_grid(n, 256 * 16);
+    double* partial = static_cast<double*>(workspace);
+    stats_partial_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, n, partial);
+    LOCATE_LAUNCH_CHECK("locate_norm_stats(partial)");
+    stats_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(partial, grid, n, stats);
+    LOCATE_LAUNCH_CHECK("locate_norm_stats(final)");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply: out = (x - mu) * y[p] / s + b[c];  optional second output act = RootTanh(out)
+//   (the DeepResidualConv that follows every block-input norm starts with RootTanh, conv.py:22-24)
+// ---------------------------------------------------------------------------------------------
+template <bool ACT>
+__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                         const float* __restrict__ scale, int scale_per_sample,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         float* __restrict__ act, int64_t planes, int C, int hw) {
+    const float mu = stats[0], s = stats[1];
+    const int64_t n = planes * hw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((hw & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        float4* a4 = reinterpret_cast<float4*>(act);
+        const int hw4 = hw >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+            const int64_t p = i / hw4;
+            const int c = (int)(p % C);
+            const float y = scale[scale_per_sample ? p : c], b = bias[c];
+            const float4 v = x4[i];
+            float4 o;
+            o.x = (v.x - mu) * y / s + b; o.y = (v.y - mu) * y / s + b;
+            o.z = (v.z - mu) * y / s + b; o.w = (v.w - mu) * y / s + b;
+            o4[i] = o;
+            if (ACT) {
+                float4 r;
+                r.x = roottanh_f(o.x); r.y = roottanh_f(o.y); r.z = roottanh_f(o.z); r.w = roottanh_f(o.w);
+                a4[i] = r;
+            }
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = i / hw;
+        const int c = (int)(p % C);
+        const float y = scale[scale_per_sample ? p : c];
+        const float o = (x[i] - mu) * y / s + bias[c];
+        out[i] = o;
+        if (ACT) act[i] = roottanh_f(o);
+    }
+}
+
+LOCATE_API int locate_norm_apply_fwd(const float* x, const float* stats, const float* scale, int scale_per_sample,
+                                     const float* bias, float* out, float* act_out, int B, int C, int hw, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0, "locate_norm_apply_fwd: bad shape");
+    const int64_t planes = (int64_t)B * C;
+    const int grid = stream_grid(planes * hw, 1024);
+    if (act_out)
+        norm_apply_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(x, stats, scale, scale_per_sample, bias, out, act_out,
+                                                                    planes, C, hw);
+    else
+        norm_apply_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(x, stats, scale, scale_per_sample, bias, out, nullptr,
+                                                                     planes, C, hw);
+    LOCATE_LAUNCH_CHECK("locate_norm_apply_fwd");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+//   pass 1 (one wave per plane):   S1[p] = sum g,  S2[p] = sum (x - mu) g
+//   pass 2 (one block):            dbias[c], dscale, consts = { mean(y g / s), dz / ((N-1) s) }
+//   pass 3 (element-wise):         dx = y[p] g / s - consts[0] + consts[1] (x - mu)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ stats, float* __restrict__ S1,
+                                                             float* __restrict__ S2, int64_t planes, int hw) {
+    const float mu = stats[0];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = wave; p < planes; p += nwaves) {
+        const int64_t base = p * hw;
+        float s1 = 0.0f, s2 = 0.0f;
+        if ((hw & 3) == 0) {
+            const float4* x4 = reinterpret_cast<const float4*>(x + base);
+            const float4* g4 = reinterpret_cast<const float4*>(g + base);
+            for (int i = lane; i < (hw >> 2); i += 64) {
+                const float4 xv = x4[i], gv = g4[i];
+                s1 += (gv.x + gv.y) + (gv.z + gv.w);
+                s2 += ((xv.x - mu) * gv.x + (xv.y - mu) * gv.y) + ((xv.z - mu) * gv.z + (xv.w - mu) * gv.w);
+            }
+        } else {
+            for (int i = lane; i < hw; i += 64) {
+                const float gv = g[base + i];
+                s1 += gv;
+                s2 = fmaf(x[base + i] - mu, gv, s2);
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            S1[p] = s1;
+            S2[p] = s2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) norm_bwd_final_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                              const float* __restrict__ stats, const float* __restrict__ scale,
+                                                              int scale_per_sample, float* __restrict__ dscale,
+                                                              float* __restrict__ dbias, float* __restrict__ consts, int B,
+                                                              int C, int hw) {
+    __shared__ double scratch[16];
+    const double s = (double)stats[1];
+    const int64_t planes = (int64_t)B * C;
+    const double n = (double)planes * (double)hw;
+    double sum_yg = 0.0, sum_yxg = 0.0;
+    // channel-wise reductions over the batch (each thread owns whole channels)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double db = 0.0, dy = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const int64_t p = (int64_t)b * C + c;
+            const double s1 = S1[p], s2 = S2[p];
+            const double y = scale[scale_per_sample ? p : c];
+            db += s1;
+            if (scale_per_sample)
+                dscale[p] = (float)(s2 / s);
+            else
+                dy += s2;
+            sum_yg += y * s1;
+            sum_yxg += y * s2;
+        }
+        dbias[c] = (float)db;
+        if (!scale_per_sample) dscale[c] = (float)(dy / s);
+    }
+    sum_yg = block_sum<double>(sum_yg, scratch);
+    sum_yxg = block_sum<double>(sum_yxg, scratch);
+    if (threadIdx.x == 0) {
+        const double dz = -sum_yxg / (s * s);
+        consts[0] = (float)(sum_yg / s / n);
+        consts[1] = (float)(dz / ((n - 1.0) * s));
+    }
+}
+
+__global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ stats, const float* __restrict__ scale,
+                                                          int scale_per_sample, const float* __restrict__ consts,
+                                                          float* __restrict__ dx, int64_t planes, int C, int hw) {
+    const float mu = stats[0], s = stats[1];
+    const float m = consts[0], k = consts[1];
+    const int64_t n = planes * hw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((hw & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* o4 = reinterpret_cast<float4*>(dx);
+        const int hw4 = hw >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+            const int64_t p = i / hw4;
+            const float y = scale[scale_per_sample ? p : (int)(p % C)];
+            const float4 xv = x4[i], gv = g4[i];
+            float4 o;
+            o.x = y * gv.x / s - m + k * (xv.x - mu); o.y = y * gv.y / s - m + k * (xv.y - mu);
+            o.z = y * gv.z / s - m + k * (xv.z - mu); o.w = y * gv.w / s - m + k * (xv.w - mu);
+            o4[i] = o;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = i / hw;
+        const float y = scale[scale_per_sample ? p : (int)(p % C)];
+        dx[i] = y * g[i] / s - m + k * (x[i] - mu);
+    }
+}
+
+LOCATE_API size_t locate_norm_bwd_workspace_bytes(int B, int C) {
+    return ((size_t)B * C * 2 + 4) * sizeof(float);
+}
+
+// dscale: [C] (scale_per_sample = 0) or [B*C];  dbias: [C].  Both overwritten.
+LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale,
+                               int scale_per_sample, float* dx, float* dscale, float* dbias, int B, int C, int hw,
+                               void* workspace, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd: bad shape or missing workspace");
+    const int64_t planes = (int64_t)B * C;
+    float* S1 = static_cast<float*>(workspace);
+    float* S2 = S1 + planes;
+    float* consts = S2 + planes;
+    int64_t blocks = cdiv64(planes, 4);
+    if (blocks > 4096) blocks = 4096;
+    norm_bwd_plane_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(x, g, stats, S1, S2, planes, hw);
+    LOCATE_LAUNCH_CHECK("locate_norm_bwd(plane)");
+    norm_bwd_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts,
+                                                            B, C, hw);
+    LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
+    norm_bwd_dx_kernel<<<stream_grid(planes * hw, 1024), 256, 0, as_stream(stream)>>>(x, g, stats, scale, scale_per_sample,
+                                                                                      consts, dx, planes, C, hw);
+    LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel sum over batch and space: out[c] = sum_{b,hw} g[b, c, hw]   (bias gradients of the 1x1 skip
+// convs, scale.py:28-34, and of the style Linears, linear.py:10)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int C,
+                                                          int hw, int64_t batch_stride) {
+    __shared__ double scratch[16];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    const int64_t per_c = (int64_t)B * hw;
+    for (int64_t i = threadIdx.x; i < per_c; i += blockDim.x) {
+        const int64_t b = i / hw, r = i - b * hw;
+        acc += (double)g[b * batch_stride + (int64_t)c * hw + r];
+    }
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) out[c] = (float)acc;
+}
+
+LOCATE_API int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && batch_stride >= (int64_t)C * hw, "locate_channel_sum: bad shape");
+    channel_sum_kernel<<<C, 256, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride);
+    LOCATE_LAUNCH_CHECK("locate_channel_sum");
+    return LOCATE_OK;
+}

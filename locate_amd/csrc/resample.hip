@@ -1,0 +1,163 @@
+// Skip-branch resampling and indexing ops of libs/scale.py (all HBM-bound stencils / copies):
+//   bilinear x2 upsample, align_corners=False   (scale.py:37-38)   fwd + bwd (adjoint, written as a gather)
+//   2x2 average pool, stride 2                  (scale.py:40)      fwd + bwd
+//   FeaturePooling                              (scale.py:7-16)    fwd + bwd - a RAW memory view: averages r
+//       ADJACENT FLAT elements (neighbouring pixels along W), not channel groups.  Bit-exact indexing.
+#include "common.h"
+
+// source index / weight of ATen's upsample_bilinear2d for scale 2, align_corners = False:
+//   src = 0.5 * (dst + 0.5) - 0.5, clamped at 0;  i0 = floor(src), i1 = i0 + (i0 < size-1), l1 = src - i0
+__device__ __forceinline__ void bil_src(int dst, int size, int& i0, int& i1, float& l0, float& l1) {
+    float src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int64_t planes, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t n = planes * OH * OW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ox = (int)(i % OW);
+        const int64_t t = i / OW;
+        const int oy = (int)(t % OH);
+        const int64_t p = t / OH;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bil_src(oy, H, y0, y1, ly0, ly1);
+        bil_src(ox, W, x0, x1, lx0, lx1);
+        const float* xp = x + p * H * W;
+        y[i] = ly0 * (lx0 * xp[y0 * W + x0] + lx1 * xp[y0 * W + x1]) + ly1 * (lx0 * xp[y1 * W + x0] + lx1 * xp[y1 * W + x1]);
+    }
+}
+
+// adjoint as a gather: input pixel (iy, ix) collects from output rows 2iy-1 .. 2iy+2 (and columns likewise)
+__device__ __forceinline__ float bil_weight_to(int dst, int size, int target) {
+    int i0, i1;
+    float l0, l1;
+    bil_src(dst, size, i0, i1, l0, l1);
+    float w = 0.0f;
+    if (i0 == target) w += l0;
+    if (i1 == target) w += l1;
+    return w;
+}
+
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                             int64_t planes, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t n = planes * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ix = (int)(i % W);
+        const int64_t t = i / W;
+        const int iy = (int)(t % H);
+        const int64_t p = t / H;
+        const float* gp = gy + p * OH * OW;
+        float wy[4], wx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+            wy[k] = (oy >= 0 && oy < OH) ? bil_weight_to(oy, H, iy) : 0.0f;
+            wx[k] = (ox >= 0 && ox < OW) ? bil_weight_to(ox, W, ix) : 0.0f;
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wy[a] == 0.0f) continue;
+            const int oy = 2 * iy - 1 + a;
+            float row = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = 2 * ix - 1 + b;
+                if (wx[b] != 0.0f) row = fmaf(wx[b], gp[oy * OW + ox], row);
+            }
+            acc = fmaf(wy[a], row, acc);
+        }
+        gx[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
+                                                           int H, int W) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t n = planes * OH * OW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ox = (int)(i % OW);
+        const int64_t t = i / OW;
+        const int oy = (int)(t % OH);
+        const int64_t p = t / OH;
+        const float* xp = x + p * H * W + (2 * oy) * W + 2 * ox;
+        y[i] = ((xp[0] + xp[1]) + (xp[W] + xp[W + 1])) * 0.25f;
+    }
+}
+
+__global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                           int64_t planes, int H, int W) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t n = planes * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ix = (int)(i % W);
+        const int64_t t = i / W;
+        const int iy = (int)(t % H);
+        const int64_t p = t / H;
+        const int oy = iy >> 1, ox = ix >> 1;
+        gx[i] = (oy < OH && ox < OW) ? gy[p * OH * OW + oy * OW + ox] * 0.25f : 0.0f;
+    }
+}
+
+// y[k] = mean(x[r k .. r k + r - 1]) over the flat buffer;  dx[r k + j] = g[k] / r
+__global__ void __launch_bounds__(256) feature_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               int64_t n_out, int r) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float inv = 1.0f / (float)r;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        float acc = 0.0f;
+        for (int j = 0; j < r; ++j) acc += x[i * r + j];
+        y[i] = r == 2 ? acc * 0.5f : acc / (float)r;
+        (void)inv;
+    }
+}
+
+__global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                               int64_t n_out, int r) {
+    const int64_t n = n_out * r;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gx[i] = gy[i / r] / (float)r;
+}
+
+#define RESAMPLE_ENTRY(NAME, KERNEL, WORK)                                                                       \
+    LOCATE_API int NAME(const float* a, float* b, int64_t planes, int H, int W, void* stream) {                  \
+        LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0, #NAME ": bad shape");                                       \
+        KERNEL<<<stream_grid((WORK), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);                     \
+        LOCATE_LAUNCH_CHECK(#NAME);                                                                              \
+        return LOCATE_OK;                                                                                        \
+    }
+
+// x: [planes, H, W] -> y: [planes, 2H, 2W]
+RESAMPLE_ENTRY(locate_upsample2x_fwd, upsample2x_fwd_kernel, planes * 4 * H * W)
+// gy: [planes, 2H, 2W] -> gx: [planes, H, W]
+RESAMPLE_ENTRY(locate_upsample2x_bwd, upsample2x_bwd_kernel, planes * H * W)
+// x: [planes, H, W] -> y: [planes, H/2, W/2]
+RESAMPLE_ENTRY(locate_avgpool2_fwd, avgpool2_fwd_kernel, planes * (H / 2) * (W / 2))
+// gy: [planes, H/2, W/2] -> gx: [planes, H, W]   (H, W are the INPUT sizes of the forward)
+RESAMPLE_ENTRY(locate_avgpool2_bwd, avgpool2_bwd_kernel, planes * H * W)
+
+LOCATE_API int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, int r, void* stream) {
+    LOCATE_REQUIRE(n_out > 0 && r > 0, "locate_feature_pool_fwd: bad shape");
+    feature_pool_fwd_kernel<<<stream_grid(n_out, 256), 256, 0, as_stream(stream)>>>(x, y, n_out, r);
+    LOCATE_LAUNCH_CHECK("locate_feature_pool_fwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, void* stream) {
+    LOCATE_REQUIRE(n_out > 0 && r > 0, "locate_feature_pool_bwd: bad shape");
+    feature_pool_bwd_kernel<<<stream_grid(n_out * r, 256), 256, 0, as_stream(stream)>>>(gy, gx, n_out, r);
+    LOCATE_LAUNCH_CHECK("locate_feature_pool_bwd");
+    return LOCATE_OK;
+}

@@ -1,0 +1,247 @@
+// Spectral normalisation state machine (reference libs/spectral_norm.py:8-32,57-59), pure HBM traffic:
+// on EVERY forward, per wrapped weight W_bar viewed as [h, wd] (h = shape[0], i.e. C_in for ConvTranspose):
+//     t = W^T u ;  v <- t / (|t| + 1e-12) ;  s = W v ;  u <- s / (|s| + 1e-12) ;  sigma = u . (W v)
+// Three passes over W in the reference (two GEMVs + a third for sigma) plus a full-size W_bar/sigma write;
+// here: two passes (column sums, row dots; W v = (W t)/(|t|+eps) by linearity, sigma = u . s from the same s)
+// and no normalised copy (1/sigma is folded into the conv's weight panel, conv.hip).
+//
+// The kernels take a table of layers so that ALL spectral-norm layers of a network are advanced by the same
+// four launches (blockIdx.y = layer; blocks beyond a layer's own work exit at once).  u, v are updated in
+// place; sigma[0] = sigma, sigma[1] = 1/sigma; wv = W v is kept for the gradient of u.
+//
+// Backward of W_n = W_bar / sigma with sigma = u . (W_bar v)   (the reference's autograd sees
+// the u, v left by the LATEST forward because they are overwritten through .data - oracle SigmaFn):
+//     dsigma = -<G, W_bar> / sigma^2
+//     dW_bar = G / sigma + dsigma * u v^T ;   du = dsigma * (W v)_k ;   dv = dsigma * W^T u
+#include "common.h"
+
+struct SnLayer {
+    const float* w;   // [h, wd] row-major (W_bar)
+    float* u;         // [h]
+    float* v;         // [wd]
+    float* sigma;     // [2]
+    float* wv;        // [h]
+    float* t;         // [wd]     scratch: W^T u
+    float* s;         // [h]      scratch: W t
+    float* tpart;     // [nchunk][wd] scratch: partial column sums
+    int h, wd, nchunk, pad;
+};
+
+#define SN_ROWS 64      // rows per column-sum chunk
+#define SN_COLS 256     // columns per block
+
+template <bool BATCHED>
+__device__ __forceinline__ SnLayer sn_get(const SnLayer& single, const SnLayer* table) {
+    return BATCHED ? table[blockIdx.y] : single;
+}
+
+// tpart[chunk][col] = sum_{i in chunk} W[i][col] * u[i]
+template <bool BATCHED>
+__global__ void __launch_bounds__(SN_COLS) sn_colsum_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+    const SnLayer L = sn_get<BATCHED>(single, table);
+    const int nstrip = (L.wd + SN_COLS - 1) / SN_COLS;
+    if ((int)blockIdx.x >= nstrip * L.nchunk) return;
+    const int strip = blockIdx.x % nstrip, chunk = blockIdx.x / nstrip;
+    const int col = strip * SN_COLS + threadIdx.x;
+    const int i0 = chunk * SN_ROWS;
+    const int i1 = min(i0 + SN_ROWS, L.h);
+    if (col >= L.wd) return;
+    float acc = 0.0f;
+    for (int i = i0; i < i1; ++i) acc = fmaf(L.w[(int64_t)i * L.wd + col], L.u[i], acc);
+    L.tpart[(int64_t)chunk * L.wd + col] = acc;
+}
+
+// t[col] = sum_chunk tpart[chunk][col]
+template <bool BATCHED>
+__global__ void __launch_bounds__(SN_COLS) sn_tsum_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+    const SnLayer L = sn_get<BATCHED>(single, table);
+    const int col = blockIdx.x * SN_COLS + threadIdx.x;
+    if (col >= L.wd) return;
+    float acc = 0.0f;
+    for (int c = 0; c < L.nchunk; ++c) acc += L.tpart[(int64_t)c * L.wd + col];
+    L.t[col] = acc;
+}
+
+// s[row] = W[row, :] . t     (one wave per row)
+template <bool BATCHED>
+__global__ void __launch_bounds__(256) sn_rowdot_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+    const SnLayer L = sn_get<BATCHED>(single, table);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= L.h) return;
+    const int lane = threadIdx.x & 63;
+    const float* wr = L.w + (int64_t)row * L.wd;
+    float acc = 0.0f;
+    for (int j = lane; j < L.wd; j += 64) acc = fmaf(wr[j], L.t[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) L.s[row] = acc;
+}
+
+// one block per layer: normalise and publish u, v, sigma, wv
+template <bool BATCHED>
+__global__ void __launch_bounds__(256) sn_finalize_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+    __shared__ double scratch[16];
+    const SnLayer L = sn_get<BATCHED>(single, table);
+    const float eps = 1e-12f;
+    double a = 0.0;
+    for (int j = threadIdx.x; j < L.wd; j += blockDim.x) a += (double)L.t[j] * (double)L.t[j];
+    a = block_sum<double>(a, scratch);
+    const float nt = (float)sqrt(a);
+    const float dt = nt + eps;
+    for (int j = threadIdx.x; j < L.wd; j += blockDim.x) L.v[j] = L.t[j] / dt;
+    double b = 0.0;
+    for (int i = threadIdx.x; i < L.h; i += blockDim.x) {
+        const float si = L.s[i] / dt;     // (W v)[i]
+        b += (double)si * (double)si;
+    }
+    b = block_sum<double>(b, scratch);
+    const float ns = (float)sqrt(b);
+    const float ds = ns + eps;
+    double sg = 0.0;
+    for (int i = threadIdx.x; i < L.h; i += blockDim.x) {
+        const float si = L.s[i] / dt;
+        const float ui = si / ds;
+        L.u[i] = ui;
+        L.wv[i] = si;
+        sg += (double)ui * (double)si;
+    }
+    sg = block_sum<double>(sg, scratch);
+    if (threadIdx.x == 0) {
+        L.sigma[0] = (float)sg;
+        L.sigma[1] = (float)(1.0 / sg);
+    }
+}
+
+static inline int sn_nchunk(int h) { return (h + SN_ROWS - 1) / SN_ROWS; }
+
+// scratch floats needed for one layer: t[wd] + s[h] + tpart[nchunk*wd]
+LOCATE_API size_t locate_sn_workspace_bytes(int h, int wd) {
+    return ((size_t)wd + h + (size_t)sn_nchunk(h) * wd) * sizeof(float);
+}
+
+static SnLayer sn_make(const float* w, float* u, float* v, float* sigma, float* wv, int h, int wd, float* ws) {
+    SnLayer L;
+    L.w = w; L.u = u; L.v = v; L.sigma = sigma; L.wv = wv;
+    L.h = h; L.wd = wd; L.nchunk = sn_nchunk(h); L.pad = 0;
+    L.t = ws; L.s = ws + wd; L.tpart = ws + wd + h;
+    return L;
+}
+
+// One power iteration for one layer.  sigma: 2 floats, wv: h floats, workspace: locate_sn_workspace_bytes(h, wd).
+LOCATE_API int locate_sn_power_iter(const float* w, float* u, float* v, float* sigma, float* wv, int h, int wd,
+                                    void* workspace, void* stream) {
+    LOCATE_REQUIRE(h > 0 && wd > 0 && w && u && v && sigma && wv && workspace, "locate_sn_power_iter: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const SnLayer L = sn_make(w, u, v, sigma, wv, h, wd, static_cast<float*>(workspace));
+    const int nstrip = (wd + SN_COLS - 1) / SN_COLS;
+    sn_colsum_kernel<false><<<nstrip * L.nchunk, SN_COLS, 0, st>>>(L, nullptr);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter(colsum)");
+    sn_tsum_kernel<false><<<nstrip, SN_COLS, 0, st>>>(L, nullptr);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter(tsum)");
+    sn_rowdot_kernel<false><<<(h + 3) / 4, 256, 0, st>>>(L, nullptr);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter(rowdot)");
+    sn_finalize_kernel<false><<<1, 256, 0, st>>>(L, nullptr);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter(finalize)");
+    return LOCATE_OK;
+}
+
+// Batched form: `table` is a DEVICE array of `n_layers` records of 9 x 8 bytes:
+//   { w, u, v, sigma, wv, t, s, tpart (pointers), (h | wd << 32), (nchunk) } - see locate_sn_table_record_bytes().
+// max_h / max_wd: maxima over the table (grid sizing).  Four launches advance every layer.
+LOCATE_API size_t locate_sn_table_record_bytes(void) { return sizeof(SnLayer); }
+
+LOCATE_API int locate_sn_power_iter_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream) {
+    LOCATE_REQUIRE(table && n_layers > 0 && max_h > 0 && max_wd > 0, "locate_sn_power_iter_batched: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const SnLayer* tab = static_cast<const SnLayer*>(table);
+    SnLayer dummy = {};
+    const int nstrip = (max_wd + SN_COLS - 1) / SN_COLS;
+    sn_colsum_kernel<true><<<dim3(nstrip * sn_nchunk(max_h), n_layers), SN_COLS, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(colsum)");
+    sn_tsum_kernel<true><<<dim3(nstrip, n_layers), SN_COLS, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(tsum)");
+    sn_rowdot_kernel<true><<<dim3((max_h + 3) / 4, n_layers), 256, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(rowdot)");
+    sn_finalize_kernel<true><<<dim3(1, n_layers), 256, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(finalize)");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sn_inner_kernel(const float* __restrict__ g, const float* __restrict__ w, int64_t n,
+                                                       double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (double)g[i] * (double)w[i];
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// dw = g / sigma + dsigma * u v^T ; block 0 also writes du = dsigma * wv and consts[0] = dsigma
+__global__ void __launch_bounds__(256) sn_dw_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                    const float* __restrict__ v, const float* __restrict__ sigma,
+                                                    const float* __restrict__ wv, const double* __restrict__ partial,
+                                                    int npartial, float* __restrict__ dw, float* __restrict__ du,
+                                                    float* __restrict__ dsigma_out, int h, int wd) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
+    acc = block_sum<double>(acc, scratch);
+    const float sg = sigma[0];
+    const float dsg = (float)(-acc / ((double)sg * (double)sg));
+    const int64_t n = (int64_t)h * wd;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
+        dw[i] = g[i] / sg + dsg * u[r] * v[c];
+    }
+    if (blockIdx.x == 0) {
+        if (du)
+            for (int i = threadIdx.x; i < h; i += blockDim.x) du[i] = dsg * wv[i];
+        if (threadIdx.x == 0) dsigma_out[0] = dsg;
+    }
+}
+
+__global__ void __launch_bounds__(SN_COLS) sn_dv_kernel(const float* __restrict__ t, const float* __restrict__ dsigma,
+                                                        float* __restrict__ dv, int wd) {
+    const int col = blockIdx.x * SN_COLS + threadIdx.x;
+    if (col < wd) dv[col] = dsigma[0] * t[col];
+}
+
+LOCATE_API size_t locate_sn_bwd_workspace_bytes(int h, int wd) {
+    return 512 * sizeof(double) + 16 + locate_sn_workspace_bytes(h, wd);
+}
+
+// g: gradient w.r.t. the normalised weight W_bar/sigma (same layout as W_bar).  sigma: the [2] buffer of the
+// forward being differentiated; wv: that forward's W v; u, v: CURRENT (latest) state.  du / dv may be null.
+LOCATE_API int locate_sn_weight_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma,
+                                    const float* wv, float* dw, float* du, float* dv, int h, int wd, void* workspace,
+                                    void* stream) {
+    LOCATE_REQUIRE(h > 0 && wd > 0 && g && w && u && v && sigma && dw && workspace, "locate_sn_weight_bwd: bad arguments");
+    LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd: du requested without the saved W v");
+    hipStream_t st = as_stream(stream);
+    double* partial = static_cast<double*>(workspace);
+    float* dsig = reinterpret_cast<float*>(partial + 512);
+    float* ws = dsig + 4;
+    const int64_t n = (int64_t)h * wd;
+    int nb = stream_grid(n, 1024);
+    if (nb > 512) nb = 512;
+    sn_inner_kernel<<<nb, 256, 0, st>>>(g, w, n, partial);
+    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(inner)");
+    sn_dw_kernel<<<stream_grid(n, 1024), 256, 0, st>>>(g, u, v, sigma, wv, partial, nb, dw, du, dsig, h, wd);
+    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(dw)");
+    if (dv) {
+        // dv = dsigma * W^T u (latest u): reuse the column-sum kernels
+        const SnLayer L = sn_make(w, const_cast<float*>(u), nullptr, nullptr, nullptr, h, wd, ws);
+        const int nstrip = (wd + SN_COLS - 1) / SN_COLS;
+        sn_colsum_kernel<false><<<nstrip * L.nchunk, SN_COLS, 0, st>>>(L, nullptr);
+        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(colsum)");
+        sn_tsum_kernel<false><<<nstrip, SN_COLS, 0, st>>>(L, nullptr);
+        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(tsum)");
+        sn_dv_kernel<<<nstrip, SN_COLS, 0, st>>>(L.t, dsig, dv, wd);
+        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(dv)");
+    }
+    return LOCATE_OK;
+}

@@ -1,0 +1,188 @@
+"""Generator / Discriminator: drop-in nn.Modules with the reference's constructor behaviour, forward
+signatures, `g_in` attribute and `state_dict()` key layout (reference libs/models.py:12-97), and the model
+set-up helper of libs/utils.py:116-150.  Configuration comes from `locate_amd.config` instead of import-time
+constants.  Seeded construction reproduces the reference's RNG draw order (tests/golden/g10_init_*.npz)."""
+import torch
+from torch import nn
+
+from .config import get_default
+from .nn import BlockBlock, DeepResidualConv, InPlaceNorm, ResModule, Scale, SpectralNorm, _identity
+from . import ops
+
+
+def _quadnorm(number):
+    return number // 4 * 4
+
+
+def generator_features(cfg):
+    """[Z, w_{n-1}, ..., w_0] with w_idx = quadnorm(GEN_FEATURES * FACTOR^(idx - n)) (models.py:16-22,43-52)."""
+    n = cfg.layers - 1
+    widths = [_quadnorm(int(cfg.gen_features * cfg.factor ** (idx - n))) for idx in range(n - 1, -1, -1)]
+    return [cfg.input_vector_z] + widths
+
+
+def discriminator_features(cfg):
+    """[w_0, ..., w_{n-1}, w_{n-1}] with w_idx = quadnorm(DIS_FEATURES * FACTOR^(idx + 1 - n)) (models.py:25-31,76-78)."""
+    n = cfg.layers - 1
+    widths = [_quadnorm(int(cfg.dis_features * cfg.factor ** ((idx + 1) - n))) for idx in range(n)]
+    return widths + [widths[-1]]
+
+
+class SpectralNormBatch:
+    """All SpectralNorm layers of one network advanced by four launches (blockIdx.y = layer) at the start of a
+    forward instead of four launches per layer.  Equivalent to the reference's per-layer update because W_bar, u
+    and v of a layer only change at optimizer steps and every wrapped layer runs exactly once per model forward."""
+
+    def __init__(self, model):
+        self.layers = [m for m in model.modules() if isinstance(m, SpectralNorm)]
+        self._key = None
+        self._table = None
+        self._meta = None
+
+    def _build(self, device):
+        import struct
+        from ._lib import lib
+        L = lib()
+        rec = L.locate_sn_table_record_bytes()
+        assert rec == 80, rec
+        scratch_sizes = []
+        for sn in self.layers:
+            w = sn.module.weight_bar
+            h = w.shape[0]
+            wd = w.numel() // h
+            scratch_sizes.append((h, wd, (h + 63) // 64))
+        total = sum(wd + h + nch * wd for h, wd, nch in scratch_sizes)
+        self._scratch = torch.empty(total, dtype=torch.float32, device=device)
+        self._meta = scratch_sizes
+        self.max_h = max(h for h, _, _ in scratch_sizes)
+        self.max_wd = max(wd for _, wd, _ in scratch_sizes)
+        self._rec = rec
+        self._struct = struct.Struct("<8Q4i")
+
+    def run(self):
+        """Power iteration for every layer; leaves (sigma, wv) on each layer for its next forward."""
+        from ._lib import check, lib
+        if not self.layers:
+            return
+        dev = self.layers[0].module.weight_bar.device
+        if self._meta is None:
+            self._build(dev)
+        n = len(self.layers)
+        key = tuple((sn.module.weight_bar.data_ptr(), sn.module.weight_u.data_ptr(), sn.module.weight_v.data_ptr())
+                    for sn in self.layers)
+        if key != self._key:
+            # persistent output buffers: the kernels write here, every forward takes its own copy below
+            tot_h = sum(h for h, _, _ in self._meta)
+            self._sig = torch.empty(n, 2, dtype=torch.float32, device=dev)
+            self._wvs = torch.empty(tot_h, dtype=torch.float32, device=dev)
+            buf = bytearray()
+            off, hoff = 0, 0
+            base = self._scratch.data_ptr()
+            for i, (sn, (h, wd, nch)) in enumerate(zip(self.layers, self._meta)):
+                m = sn.module
+                t = base + 4 * off
+                s = t + 4 * wd
+                tp = s + 4 * h
+                buf += self._struct.pack(m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(),
+                                         self._sig.data_ptr() + 8 * i, self._wvs.data_ptr() + 4 * hoff, t, s, tp, h, wd, nch, 0)
+                off += wd + h + nch * wd
+                hoff += h
+            host = torch.frombuffer(buf, dtype=torch.uint8)
+            self._table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+            self._table.copy_(host)
+            self._key = key
+        check(lib().locate_sn_power_iter_batched(self._table.data_ptr(), n, self.max_h, self.max_wd,
+                                                 torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
+        sig, wvs = self._sig.clone(), self._wvs.clone()   # this forward's sigma / W v (kept for its backward)
+        hoff = 0
+        for i, (sn, (h, _, _)) in enumerate(zip(self.layers, self._meta)):
+            sn._pre = (sig[i], wvs[hoff:hoff + h])
+            hoff += h
+
+
+class _NetBase(nn.Module):
+    batched_spectral_norm = False   # see SpectralNormBatch; off by default (per-layer update inside each layer)
+
+    def _sn_prologue(self):
+        if self.batched_spectral_norm:
+            if getattr(self, "_sn_batch", None) is None:
+                object.__setattr__(self, "_sn_batch", SpectralNormBatch(self))
+            self._sn_batch.run()
+
+
+class Generator(_NetBase):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or get_default()
+        self.cfg = cfg
+        clayers = cfg.layers - 1
+        strides = [cfg.g_stride] * clayers
+        feature_list = generator_features(cfg)
+        self.input_block = _identity                      # START_LAYER = 0 (config.py:39)
+        self.conv_block = BlockBlock(len(strides), 2, feature_list, strides, True, True, cfg=cfg)
+        self.out_conv = DeepResidualConv(self.conv_block.out_features, 3, False, 1, False, 2, 1, cfg=cfg)
+        self.g_in = feature_list[0]
+        # a plain tensor like in the reference (models.py:59): not a Parameter, not in state_dict()
+        self.noise = torch.randn(1, cfg.input_vector_z, 2, 2)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.noise = fn(self.noise)                       # the reference creates it on DEVICE; follow .to()/.cuda()
+        return out
+
+    def forward(self, function_input):
+        self._sn_prologue()
+        expanded_noise = self.noise.expand(function_input.size(0), -1, -1, -1).contiguous()
+        conv_out = self.conv_block(self.input_block(expanded_noise), function_input)
+        return ops.tanh(self.out_conv(conv_out))
+
+
+class Discriminator(_NetBase):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or get_default()
+        self.cfg = cfg
+        clayers = cfg.layers - 1
+        strides = [cfg.d_stride] * clayers
+        feature_list = discriminator_features(cfg)
+        stem = ResModule(Scale(3, feature_list[0], 2, False), DeepResidualConv(3, feature_list[0], False, 2, False, 2, 1, cfg=cfg))
+        block_block = BlockBlock(len(strides), cfg.image_size // 2, feature_list, strides, False, cfg=cfg)
+        head = DeepResidualConv(block_block.out_features, 1, False, 1, False, 2, 1, cfg=cfg)   # END_LAYER = 1
+        self.main = nn.Sequential(stem, block_block, head)
+
+    def forward(self, function_input):
+        self._sn_prologue()
+        return self.main(function_input)
+
+
+def init(module):
+    """libs/utils.py:116-130 as it actually behaves when applied before the first forward: wrapped convs have no
+    `.weight` yet, so only norm weights (~U(0.998, 1.002)) and biases (0) are touched."""
+    if "norm" not in module.__class__.__name__.lower():
+        try:
+            nn.init.orthogonal_(module.weight.data)
+        except AttributeError:
+            pass
+    else:
+        try:
+            nn.init.uniform_(module.weight.data, 0.998, 1.002)
+        except AttributeError:
+            pass
+    try:
+        nn.init.constant_(module.bias.data, 0)
+    except AttributeError:
+        pass
+
+
+def get_model(model, learning_rate, device, cfg=None):
+    """libs/utils.py:146-150: move, init, build the Nadam optimizer."""
+    from .optim import Nadam
+    cfg = cfg or getattr(model, "cfg", None) or get_default()
+    model.apply(init)          # RNG draws happen on the CPU generator, like the CPU reference
+    model = model.to(device)
+    opt = Nadam(model.parameters(), lr=learning_rate, betas=(cfg.beta1, cfg.beta2))
+    return model, opt
+
+
+def parameter_count(net):
+    return sum(p.numel() for p in net.parameters() if p.requires_grad)

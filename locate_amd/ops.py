@@ -1,0 +1,468 @@
+"""Operator layer: torch.autograd.Functions whose forward AND backward are the gfx950 kernels behind the C ABI.
+
+Mirrors the reference's operator-level boundary: `root_tanh` (libs/activation.py:39),
+`mean_sub_mul_div_add`/InPlaceNorm (libs/inplace_norm.py:31), `residual_function` (libs/merge.py:43) and the
+spectral-normalised convolutions (libs/spectral_norm.py:57-59 + the wrapped torch.nn conv/linear forward).
+PyTorch is used for device memory, streams and the autograd graph only - no ATen arithmetic on the hot path.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+_IntArr12 = ctypes.c_int * 12
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("%s must be a float32 CUDA/HIP tensor (the kernels run on MI355X only), got %s on %s"
+                        % (what, t.dtype, t.device))
+    return t
+
+
+def _c(t, what="tensor"):
+    _chk(t, what)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------------
+# RootTanh / tanh
+# ------------------------------------------------------------------------------------------------
+class RootTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x, "root_tanh input")
+        y = torch.empty_like(x)
+        check(lib().locate_roottanh_fwd(_p(x), _p(y), x.numel(), _stream()), "locate_roottanh_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(x)
+        check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), _stream()), "locate_roottanh_bwd")
+        return gx
+
+
+class TanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x, "tanh input")
+        y = torch.empty_like(x)
+        check(lib().locate_tanh_fwd(_p(x), _p(y), x.numel(), _stream()), "locate_tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(y)
+        check(lib().locate_tanh_bwd(_p(y), _p(g), _p(gx), y.numel(), _stream()), "locate_tanh_bwd")
+        return gx
+
+
+root_tanh = RootTanhFn.apply
+tanh = TanhFn.apply
+
+
+# ------------------------------------------------------------------------------------------------
+# InPlaceNorm
+# ------------------------------------------------------------------------------------------------
+class InPlaceNormFn(torch.autograd.Function):
+    """out = (x - mean(x)) * scale / std(x) + bias with global scalar statistics.  With `with_act` the
+    forward returns RootTanh(out) instead (out is kept only for the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias, with_act):
+        x = _c(x, "norm input")
+        B, C = x.shape[0], x.shape[1]
+        hw = x.numel() // (B * C)
+        per_sample = scale.numel() == B * C and (B > 1 and scale.shape[0] == B)
+        if not per_sample and scale.numel() != C:
+            raise ValueError("norm scale must have C or B*C elements, got %s for input %s" % (tuple(scale.shape), tuple(x.shape)))
+        scale_c, bias_c = _c(scale, "norm scale"), _c(bias, "norm bias")
+        L = lib()
+        st = _stream()
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device)
+        check(L.locate_norm_stats(_p(x), x.numel(), _p(stats), _p(ws), st), "locate_norm_stats")
+        out = torch.empty_like(x)
+        act = torch.empty_like(x) if with_act else None
+        check(L.locate_norm_apply_fwd(_p(x), _p(stats), _p(scale_c), int(per_sample), _p(bias_c), _p(out), _p(act), B, C, hw,
+                                      st), "locate_norm_apply_fwd")
+        ctx.per_sample, ctx.with_act = per_sample, with_act
+        ctx.scale_shape, ctx.bias_shape = scale.shape, bias.shape
+        if with_act:
+            ctx.save_for_backward(x, scale_c, stats, out)
+            return act
+        ctx.save_for_backward(x, scale_c, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        st = _stream()
+        g = _c(g)
+        if ctx.with_act:
+            x, scale, stats, out = ctx.saved_tensors
+            g_out = torch.empty_like(g)
+            check(L.locate_roottanh_bwd(_p(out), _p(g), _p(g_out), g.numel(), st), "locate_roottanh_bwd")
+            g = g_out
+        else:
+            x, scale, stats = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        hw = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device)
+        dbias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device)
+        ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
+        check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(dx), _p(dscale), _p(dbias), B, C, hw,
+                                _p(ws), st), "locate_norm_bwd")
+        return dx, dscale, dbias, None
+
+
+def inplace_norm(x, scale, bias, with_act=False):
+    return InPlaceNormFn.apply(x, scale, bias, with_act)
+
+
+# ------------------------------------------------------------------------------------------------
+# residual gate
+# ------------------------------------------------------------------------------------------------
+class GateFn(torch.autograd.Function):
+    """out = (gamma * a + 1) * x;  `a` has x's shape or is [B, C, 1, 1] (one value per plane)."""
+
+    @staticmethod
+    def forward(ctx, x, a, gamma):
+        x = _c(x, "gate input")
+        a = _c(a, "gate attention")
+        gamma = _c(gamma, "gate gamma")
+        planes = x.shape[0] * x.shape[1]
+        hw = x.numel() // planes
+        per_plane = a.numel() == planes and x.numel() != planes
+        if not per_plane and a.numel() != x.numel():
+            raise ValueError("gate: attention shape %s does not match input %s" % (tuple(a.shape), tuple(x.shape)))
+        out = torch.empty_like(x)
+        check(lib().locate_gate_fwd(_p(x), _p(a), int(per_plane), _p(gamma), _p(out), planes, hw, _stream()), "locate_gate_fwd")
+        ctx.save_for_backward(x, a, gamma)
+        ctx.per_plane = per_plane
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a, gamma = ctx.saved_tensors
+        g = _c(g)
+        L = lib()
+        planes = x.shape[0] * x.shape[1]
+        hw = x.numel() // planes
+        dx = torch.empty_like(x)
+        da = torch.empty_like(a)
+        dgamma = torch.empty_like(gamma)
+        ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
+        check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), _p(dgamma), planes, hw, _p(ws),
+                                _stream()), "locate_gate_bwd")
+        return dx, da, dgamma
+
+
+residual_gate = GateFn.apply
+
+
+# ------------------------------------------------------------------------------------------------
+# softmax over the last dimension
+# ------------------------------------------------------------------------------------------------
+class SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x, "softmax input")
+        n = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().locate_softmax_fwd(_p(x), _p(y), x.numel() // n, n, _stream()), "locate_softmax_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        g = _c(g)
+        n = y.shape[-1]
+        gx = torch.empty_like(y)
+        check(lib().locate_softmax_bwd(_p(y), _p(g), _p(gx), y.numel() // n, n, _stream()), "locate_softmax_bwd")
+        return gx
+
+
+softmax_lastdim = SoftmaxFn.apply
+
+
+# ------------------------------------------------------------------------------------------------
+# resampling / indexing
+# ------------------------------------------------------------------------------------------------
+class Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x, "upsample input")
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, 2 * H, 2 * W, dtype=x.dtype, device=x.device)
+        check(lib().locate_upsample2x_fwd(_p(x), _p(y), B * C, H, W, _stream()), "locate_upsample2x_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        g = _c(g)
+        gx = torch.empty(B, C, H, W, dtype=g.dtype, device=g.device)
+        check(lib().locate_upsample2x_bwd(_p(g), _p(gx), B * C, H, W, _stream()), "locate_upsample2x_bwd")
+        return gx
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x, "avgpool input")
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, H // 2, W // 2, dtype=x.dtype, device=x.device)
+        check(lib().locate_avgpool2_fwd(_p(x), _p(y), B * C, H, W, _stream()), "locate_avgpool2_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        g = _c(g)
+        gx = torch.empty(B, C, H, W, dtype=g.dtype, device=g.device)
+        check(lib().locate_avgpool2_bwd(_p(g), _p(gx), B * C, H, W, _stream()), "locate_avgpool2_bwd")
+        return gx
+
+
+class FeaturePoolFn(torch.autograd.Function):
+    """FeaturePooling: the raw-view mean over r adjacent flat elements (libs/scale.py:12-16)."""
+
+    @staticmethod
+    def forward(ctx, x, out_features):
+        x = _c(x, "feature pooling input")     # the reference's .view() requires contiguity too
+        B, C = x.shape[0], x.shape[1]
+        if C % out_features:
+            raise ValueError("FeaturePooling: %d channels not divisible by %d" % (C, out_features))
+        r = C // out_features
+        y = torch.empty((B, out_features) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        check(lib().locate_feature_pool_fwd(_p(x), _p(y), y.numel(), r, _stream()), "locate_feature_pool_fwd")
+        ctx.in_shape, ctx.r = x.shape, r
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        gx = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device)
+        check(lib().locate_feature_pool_bwd(_p(g), _p(gx), g.numel(), ctx.r, _stream()), "locate_feature_pool_bwd")
+        return gx, None
+
+
+upsample2x = Upsample2xFn.apply
+avgpool2 = AvgPool2Fn.apply
+feature_pool = FeaturePoolFn.apply
+
+
+def _copy_channels(src, dst, accumulate=False):
+    """dst[:, :C] (+)= src for NCHW tensors whose channel planes are dense (batch stride free)."""
+    B, C = src.shape[0], src.shape[1]
+    hw = src[0, 0].numel() if src.dim() > 2 else 1
+    check(lib().locate_copy_channels(_p(src), _p(dst), B, C, hw, src.stride(0), dst.stride(0), int(accumulate), _stream()),
+          "locate_copy_channels")
+
+
+def _dense_planes(t):
+    """True if t is NCHW with contiguous [C, H, W] blocks per batch element (a channel slice of a contiguous tensor)."""
+    if t.dim() < 2:
+        return False
+    expect = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != expect:
+            return False
+        expect *= size
+    return True
+
+
+class CatChannelsFn(torch.autograd.Function):
+    """torch.cat([a, b], dim=1) (libs/merge.py:15) as two strided plane copies."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a, "cat input"), _c(b, "cat input")
+        ca, cb = a.shape[1], b.shape[1]
+        out = torch.empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+        _copy_channels(a, out[:, :ca])
+        _copy_channels(b, out[:, ca:])
+        ctx.split = (ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        ca, cb = ctx.split
+        ga = torch.empty((g.shape[0], ca) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+        gb = torch.empty((g.shape[0], cb) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+        _copy_channels(g[:, :ca], ga)
+        _copy_channels(g[:, ca:], gb)
+        return ga, gb
+
+
+cat_channels = CatChannelsFn.apply
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral-normalised dense contractions
+# ------------------------------------------------------------------------------------------------
+class ConvSpec:
+    """Geometry of one wrapped torch.nn layer expressed through the regular convolution R of conv.hip.
+
+    kind 'conv'  : y = R(x);            weight [M=C_out, C=C_in, KH, KW]
+    kind 'convT' : y = R^T(x) (adjoint); weight [M=C_in, C=C_out, KH, KW]  (ConvTranspose2d layout)
+    """
+    __slots__ = ("kind", "kh", "kw", "stride", "pad_h", "pad_w")
+
+    def __init__(self, kind, kh, kw, stride, pad_h, pad_w):
+        self.kind, self.kh, self.kw, self.stride, self.pad_h, self.pad_w = kind, kh, kw, stride, pad_h, pad_w
+
+    def geometry(self, x_shape, w_shape):
+        """Returns (geom[12] of R, output shape)."""
+        B, Cx, H, W = x_shape
+        M, C = w_shape[0], w_shape[1]
+        s = self.stride
+        if self.kind == "conv":
+            if Cx != C:
+                raise ValueError("conv: input has %d channels, weight expects %d" % (Cx, C))
+            OH = (H + 2 * self.pad_h - self.kh) // s + 1
+            OW = (W + 2 * self.pad_w - self.kw) // s + 1
+            return [B, C, H, W, M, self.kh, self.kw, s, self.pad_h, self.pad_w, OH, OW], (B, M, OH, OW)
+        if Cx != M:
+            raise ValueError("convT: input has %d channels, weight expects %d" % (Cx, M))
+        # the input of the transposed conv is R's OUTPUT; R's input is the transposed conv's output
+        RH = (H - 1) * s - 2 * self.pad_h + self.kh
+        RW = (W - 1) * s - 2 * self.pad_w + self.kw
+        return [B, C, RH, RW, M, self.kh, self.kw, s, self.pad_h, self.pad_w, H, W], (B, C, RH, RW)
+
+
+def _geom(arr):
+    return _IntArr12(*arr)
+
+
+def _bs(t):
+    return t.stride(0)
+
+
+def sn_power_iteration(w_bar, u, v):
+    """One power iteration on (u, v) IN PLACE (untracked, like the reference's `.data` writes,
+    libs/spectral_norm.py:26-29).  Returns (sigma[2] = {sigma, 1/sigma}, wv[h] = W v)."""
+    L = lib()
+    h = w_bar.shape[0]
+    wd = w_bar.numel() // h
+    w = _c(w_bar.detach(), "weight_bar")
+    sigma = torch.empty(2, dtype=torch.float32, device=w.device)
+    wv = torch.empty(h, dtype=torch.float32, device=w.device)
+    ws = _ws(L.locate_sn_workspace_bytes(h, wd), w.device)
+    check(L.locate_sn_power_iter(_p(w), _p(_chk(u.detach(), "weight_u")), _p(_chk(v.detach(), "weight_v")), _p(sigma), _p(wv),
+                                 h, wd, _p(ws), _stream()), "locate_sn_power_iter")
+    return sigma, wv
+
+
+class SNConvFn(torch.autograd.Function):
+    """y = conv(x, W_bar / sigma) + bias for Conv2d / ConvTranspose2d semantics (Conv1d(k=1), Linear and the
+    (S x 1)/(1 x S) feature-attention convs are reshaped to 1x1 convs by the caller).  sigma / wv are the
+    results of THIS forward's power iteration; u, v are inputs only so that their gradients can be returned
+    (the reference's main.py:172 makes them trainable) - they are read at backward time, i.e. with the values
+    left by the latest forward, exactly like the reference's autograd does."""
+
+    @staticmethod
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec):
+        L = lib()
+        st = _stream()
+        _chk(x, "conv input")
+        if not _dense_planes(x):
+            x = x.contiguous()
+        w = _c(w_bar, "weight_bar")
+        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+        garr = _geom(geom)
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        inv_sigma = sigma[1:]
+        b = _c(bias) if bias is not None else None
+        if spec.kind == "conv":
+            ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
+            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(w), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws), st), "locate_conv_fwd")
+        else:
+            ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
+            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(w), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws), st),
+                  "locate_conv_dgrad")
+        ctx.save_for_backward(x, w, sigma, wv)
+        ctx.u, ctx.v = u, v            # live state, read at backward time
+        ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = lib()
+        st = _stream()
+        x, w, sigma, wv = ctx.saved_tensors
+        spec, garr = ctx.spec, _geom(ctx.geom)
+        _chk(gy, "conv output gradient")
+        if not _dense_planes(gy):
+            gy = gy.contiguous()
+        need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
+        gx = gw = gu = gv = gb = None
+        inv_sigma = sigma[1:]
+        if need_x:
+            gx = torch.empty_like(x)
+            if spec.kind == "conv":
+                ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
+                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(w), _p(inv_sigma), None, _p(gx), _bs(gx), _p(ws), st),
+                      "locate_conv_dgrad")
+            else:
+                ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
+                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(w), _p(inv_sigma), None, _p(gx), _bs(gx), _p(ws), st),
+                      "locate_conv_fwd")
+        if need_w or need_u or need_v:
+            g_wn = torch.empty_like(w)     # gradient w.r.t. the normalised weight W_bar / sigma
+            ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
+            if spec.kind == "conv":
+                check(L.locate_conv_wgrad(garr, _p(x), _bs(x), _p(gy), _bs(gy), _p(g_wn), _p(ws), st), "locate_conv_wgrad")
+            else:   # roles swapped: R's input is gy, R's output-gradient is x
+                check(L.locate_conv_wgrad(garr, _p(gy), _bs(gy), _p(x), _bs(x), _p(g_wn), _p(ws), st), "locate_conv_wgrad")
+            h = w.shape[0]
+            wd = w.numel() // h
+            gw = torch.empty_like(w)
+            u, v = ctx.u.detach(), ctx.v.detach()
+            gu = torch.empty_like(u) if need_u else None
+            gv = torch.empty_like(v) if need_v else None
+            ws2 = _ws(L.locate_sn_bwd_workspace_bytes(h, wd), x.device)
+            check(L.locate_sn_weight_bwd(_p(g_wn), _p(w), _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(gv), h, wd, _p(ws2),
+                                         st), "locate_sn_weight_bwd")
+            if not need_w:
+                gw = None
+        if ctx.has_bias and need_b:
+            Bn, Cn = gy.shape[0], gy.shape[1]
+            gb = torch.empty(Cn, dtype=torch.float32, device=gy.device)
+            check(L.locate_channel_sum(_p(gy), _p(gb), Bn, Cn, gy.numel() // (Bn * Cn), _bs(gy), st), "locate_channel_sum")
+        return gx, gw, gu, gv, gb, None, None, None
+
+
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None):
+    """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
+    batched update is supplied."""
+    if sigma_wv is None:
+        sigma_wv = sn_power_iteration(w_bar, u, v)
+    sigma, wv = sigma_wv
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec)

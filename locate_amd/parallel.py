@@ -1,0 +1,153 @@
+"""Data parallelism for the G+D step: one process per GPU, identical replicas, ONE exchange per optimizer
+step - the mean of every non-None parameter gradient over the ranks.
+
+The reference has no distributed code at all; this is new capability, designed for the MI355X node:
+  * `torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm); "gloo" on CPU for the tests;
+  * gradients are packed into a few large flat buckets (default 32 MiB: the xGMI mesh is point-to-point, so few
+    large collectives beat many small ones) in REVERSE parameter order, which is roughly the order in which the
+    backward pass produces them;
+  * a bucket's all-reduce is issued from a post-accumulate-grad hook as soon as its last gradient has been
+    accumulated, on a side stream, so it overlaps the rest of the backward pass; `finish()` joins the side
+    stream, flushes buckets that did not fill (parameters without gradient this step: the generator's unused
+    `i_norm.weight`s, the discriminator's u/v before they become trainable) and scatters the averaged values
+    back into the `.grad` tensors;
+  * InPlaceNorm statistics stay per replica (no second collective); spectral-norm u/v need no traffic because
+    they are a deterministic function of identical (W_bar, u).
+Parity statement: the averaged gradient equals the mean of the gradients the reference would compute on each
+rank's shard independently (tests/test_parallel_gloo.py)."""
+import torch
+import torch.distributed as dist
+
+
+def broadcast_module_state(module, src=0, extra_tensors=()):
+    """Make every rank's parameters, buffers and extra tensors (Generator.noise!) equal to rank `src`'s."""
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()) + list(extra_tensors):
+            dist.broadcast(t.data, src)
+
+
+class GradAllReducer:
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True):
+        self.params = [p for p in params]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.bucket_bytes = bucket_bytes
+        # reverse order ~ gradient production order
+        self.buckets = []          # list of lists of parameter indices
+        cur, cur_bytes = [], 0
+        for idx in reversed(range(len(self.params))):
+            p = self.params[idx]
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(idx)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {}
+        for b, idxs in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[i] = b
+        self._flat = [None] * len(self.buckets)
+        self._handles = []
+        self._ready = None
+        self._launched = None
+        self._active = False
+        self._side = None
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # ------------------------------------------------------------------------------------------
+    def begin(self):
+        """Call right before backward()."""
+        if self.world == 1:
+            return
+        self._ready = [0] * len(self.buckets)
+        self._seen = set()
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._active = True
+        self._expected = [sum(1 for i in idxs if self.params[i].requires_grad) for idxs in self.buckets]
+
+    def _make_hook(self, i):
+        def hook(p):
+            if not self._active or i in self._seen:
+                return
+            self._seen.add(i)
+            b = self.bucket_of[i]
+            self._ready[b] += 1
+            if self.overlap and self._ready[b] == self._expected[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        members = [i for i in self.buckets[b] if self.params[i].grad is not None]
+        self._launched[b] = True
+        if not members:
+            return
+        grads = [self.params[i].grad for i in members]
+        dev = grads[0].device
+        total = sum(g.numel() for g in grads)
+        flat = self._flat[b]
+        if flat is None or flat.numel() != total or flat.device != dev:
+            flat = torch.empty(total, dtype=grads[0].dtype, device=dev)
+            self._flat[b] = flat
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(torch.cuda.current_stream(dev))   # the gradients are produced on the compute stream
+            with torch.cuda.stream(self._side):
+                self._pack(flat, grads)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._pack(flat, grads)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append((b, members, work))
+
+    @staticmethod
+    def _pack(flat, grads):
+        off = 0
+        for g in grads:
+            n = g.numel()
+            flat[off:off + n].copy_(g.reshape(-1))
+            off += n
+
+    def finish(self):
+        """Call after backward(), before optimizer.step(): afterwards every .grad holds the rank mean."""
+        if self.world == 1:
+            return
+        self._active = False
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        inv = 1.0 / self.world
+        for b, members, work in self._handles:
+            flat = self._flat[b]
+            dev = flat.device
+            if dev.type == "cuda":
+                with torch.cuda.stream(self._side):
+                    work.wait()
+                    self._unpack(flat, members, inv)
+            else:
+                work.wait()
+                self._unpack(flat, members, inv)
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+        self._handles = []
+
+    def _unpack(self, flat, members, inv):
+        off = 0
+        for i in members:
+            g = self.params[i].grad
+            n = g.numel()
+            g.copy_((flat[off:off + n] * inv).view_as(g))
+            off += n

@@ -1,0 +1,91 @@
+"""One G+D training iteration: the loop body of the reference's main.py:142-172 (miniter = 1), with the loss
+glue (libs/utils.py:133-134 hinge, libs/grad_penalty.py:1-2 consistency penalty) computed by one small HIP
+kernel per phase that also emits the gradients w.r.t. the discriminator outputs.
+
+Sequencing kept from the reference, including its quirks:
+  * D-step: G forward (result detached), `dis.zero_grad()`, three D forwards in the order real / fake /
+    augmented (every forward advances the spectral-norm u, v), ONE backward over the three graphs, D Nadam step;
+  * G-step: `dis.requires_grad_(False)`, MINIBATCHES x {`gen.zero_grad()`, forward, backward} on the SAME noise
+    (only the last pass's gradients survive), G Nadam step, `dis.requires_grad_(True)` - which also makes D's
+    spectral-norm u, v trainable from the second D-step on.
+With `world_size > 1` the gradients are averaged across ranks by `locate_amd.parallel.GradAllReducer`
+(RCCL all-reduce, bucketed, on a side stream) before each optimizer step.
+"""
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def d_loss(d_true, d_fake, d_aug, gamma=100.0):
+    """Returns (losses[3] = {d_error, penalty, total}, g_true, g_fake, g_aug)."""
+    B = d_true.numel()
+    dev = d_true.device
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    g = torch.empty(3, B, dtype=torch.float32, device=dev)
+    t, f, a = (x.detach().contiguous() for x in (d_true, d_fake, d_aug))
+    check(lib().locate_d_loss(t.data_ptr(), f.data_ptr(), a.data_ptr(), B, float(gamma), losses.data_ptr(), g[0].data_ptr(),
+                              g[1].data_ptr(), g[2].data_ptr(), _stream()), "locate_d_loss")
+    return losses, g[0], g[1], g[2]
+
+
+def g_loss(d_fake):
+    B = d_fake.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=d_fake.device)
+    g = torch.empty(B, dtype=torch.float32, device=d_fake.device)
+    f = d_fake.detach().contiguous()
+    check(lib().locate_g_loss(f.data_ptr(), B, loss.data_ptr(), g.data_ptr(), _stream()), "locate_g_loss")
+    return loss, g
+
+
+class TrainStep:
+    def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None):
+        self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
+        self.penalty_gamma = penalty_gamma
+        self.minibatches = minibatches
+        self.reducer_g, self.reducer_d = reducer_g, reducer_d
+
+    def d_step(self, latent, real, aug):
+        gen, dis = self.gen, self.dis
+        with torch.no_grad():                      # main.py:146 builds a graph and drops it (.detach()); same values
+            generated = gen(latent)
+        dis.zero_grad()                            # main.py:148
+        d_true = dis(real)                         # :149
+        d_fake = dis(generated)                    # :150 (the reference negates it; the loss kernel takes it raw)
+        d_aug = dis(aug)                           # grad_penalty.py:2
+        losses, g_t, g_f, g_a = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
+        if self.reducer_d is not None:
+            self.reducer_d.begin()
+        torch.autograd.backward([d_true, d_fake, d_aug], [g_t.view_as(d_true), g_f.view_as(d_fake), g_a.view_as(d_aug)])  # :156
+        if self.reducer_d is not None:
+            self.reducer_d.finish()
+        self.dis_opt.step()                        # :159
+        return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
+                "d_gen": -d_fake.detach().view(-1), "generated": generated}
+
+    def g_step(self, latent):
+        gen, dis = self.gen, self.dis
+        dis.requires_grad_(False)                  # main.py:161
+        try:
+            for _ in range(self.minibatches):      # :162-169 (same noise, zero_grad inside the loop)
+                gen.zero_grad()
+                fake = gen(latent)
+                d_out = dis(fake)
+                loss, g = g_loss(d_out)
+                if self.reducer_g is not None:
+                    self.reducer_g.begin()
+                d_out.backward(g.view_as(d_out))
+                if self.reducer_g is not None:
+                    self.reducer_g.finish()
+            self.gen_opt.step()                    # :171
+        finally:
+            dis.requires_grad_(True)               # :172 (u, v included)
+        return {"g_error": loss[0], "fake": fake.detach()}
+
+    def __call__(self, latent, real, aug):
+        out = self.d_step(latent, real, aug)
+        out.update(self.g_step(latent))
+        return out

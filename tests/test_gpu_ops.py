@@ -1,0 +1,470 @@
+"""Parity of the gfx950 kernels (through the C ABI and the autograd layer) against the golden fixtures
+generated from the reference and against the CPU oracle on seeded inputs.  Needs an MI355X: run with -m gpu.
+Tolerances: normalised max error (max |got - want| / max |want|); fp32 per-op 1e-5 ... 1e-4 as stated per test
+(the reference's own fp32-vs-fp64 noise is <= 7e-7 on outputs, <= 1.3e-5 on gradients);
+bit-exact for indexing ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+T = torch.as_tensor
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def G_(a):
+    return T(a).to(dev())
+
+
+def sub(z, prefix):
+    return {k[len(prefix):]: T(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_device_is_gfx950_and_library_loaded():
+    from locate_amd._lib import LIB_PATH, require_gpu
+    arch, cus, wave = require_gpu()
+    assert arch.startswith("gfx950") and wave == 64 and cus >= 200, (arch, cus, wave)
+    maps = open("/proc/self/maps").read()
+    assert LIB_PATH in maps
+
+
+# ------------------------------------------------------------------------------------------------ G1
+def test_roottanh_golden_and_large():
+    from locate_amd import ops
+    from oracle import locate_oracle as O
+    z = load_golden("g1_roottanh_f32")
+    x = G_(z["x"]).requires_grad_(True)
+    y = ops.root_tanh(x)
+    y.backward(G_(z["g"]))
+    assert torch.isfinite(x.grad).all()
+    assert_close(y.cpu(), z["y"], 2e-6, "y")
+    assert_close(x.grad.cpu(), z["dx"], 2e-6, "dx")
+    z64 = load_golden("g1_roottanh_f64")     # fp64 truth: the fp32 kernel must be as close as the reference's fp32
+    x = G_(z64["x"].astype(np.float32)).requires_grad_(True)
+    y = ops.root_tanh(x)
+    y.backward(G_(z64["g"].astype(np.float32)))
+    assert_close(y.cpu(), z64["y"], 2e-6)
+    assert_close(x.grad.cpu(), z64["dx"], 2e-6)
+    # odd length (tail path) and a full-size activation
+    for n in (1, 7, 1023, 64 * 96 * 64 * 64):
+        torch.manual_seed(n)
+        xc = torch.randn(n) * 4
+        gc = torch.randn(n)
+        xr = xc.clone().requires_grad_(True)
+        O.root_tanh(xr).backward(gc)
+        xg = xc.to(dev()).requires_grad_(True)
+        yg = ops.root_tanh(xg)
+        yg.backward(gc.to(dev()))
+        assert_close(yg.cpu(), O.root_tanh(xc), 2e-6, "n=%d" % n)
+        assert_close(xg.grad.cpu(), xr.grad, 3e-6, "n=%d grad" % n)
+
+
+def test_tanh():
+    from locate_amd import ops
+    torch.manual_seed(3)
+    xc = torch.randn(5000) * 3
+    xg = xc.to(dev()).requires_grad_(True)
+    y = ops.tanh(xg)
+    g = torch.randn(5000)
+    y.backward(g.to(dev()))
+    assert_close(y.cpu(), torch.tanh(xc), 2e-6)
+    assert_close(xg.grad.cpu(), g * (1 - torch.tanh(xc) ** 2), 5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ G2
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_inplace_norm_golden(case):
+    from locate_amd import ops
+    z = load_golden("g2_inplace_norm")
+    for mode, yname in (("w", "weight"), ("s", "scale")):
+        p = "%s_%s_" % (case, mode)
+        x = G_(z[p + "x"]).requires_grad_(True)
+        y = G_(z[p + yname]).requires_grad_(True)
+        b = G_(z[p + "bias"]).requires_grad_(True)
+        out = ops.inplace_norm(x, y, b)
+        out.backward(G_(z[p + "g"]))
+        assert_close(out.cpu(), z[p + "out"], 1e-5, p + "out")
+        assert_close(x.grad.cpu(), z[p + "dx"], 3e-5, p + "dx")
+        assert_close(y.grad.cpu(), z[p + "d" + yname], 3e-5, p + "dy")
+        assert_close(b.grad.cpu(), z[p + "dbias"], 1e-5, p + "db")
+
+
+def test_inplace_norm_fused_activation_and_big():
+    from locate_amd import ops
+    from oracle import locate_oracle as O
+    torch.manual_seed(11)
+    for shape, per_sample in (((4, 6, 5, 7), False), ((8, 48, 64, 64), True), ((64, 768, 2, 2), True), ((3, 5, 1, 1), False)):
+        B, C = shape[:2]
+        x = torch.randn(shape) * 1.7 + 0.4
+        y = torch.randn(B if per_sample else 1, C, 1, 1)
+        b = torch.randn(1, C, 1, 1)
+        g = torch.randn(shape)
+        xr, yr, br = (t.clone().requires_grad_(True) for t in (x, y, b))
+        ref = O.root_tanh(O.inplace_norm(xr, yr, br))
+        ref.backward(g)
+        xg, yg, bg = (t.to(dev()).requires_grad_(True) for t in (x, y, b))
+        out = ops.inplace_norm(xg, yg, bg, True)
+        out.backward(g.to(dev()))
+        assert_close(out.cpu(), ref, 1e-5, "act %s" % (shape,))
+        assert_close(xg.grad.cpu(), xr.grad, 5e-5, "dx %s" % (shape,))
+        assert_close(yg.grad.cpu(), yr.grad, 5e-5, "dy %s" % (shape,))
+        assert_close(bg.grad.cpu(), br.grad, 5e-5, "db %s" % (shape,))
+
+
+# ------------------------------------------------------------------------------------------------ G3
+def test_residual_gate_golden():
+    from locate_amd import ops
+    z = load_golden("g3_residual")
+    for p in ("full_", "bc_"):
+        x = G_(z[p + "x"]).requires_grad_(True)
+        a = G_(z[p + "a"]).requires_grad_(True)
+        gamma = G_(z[p + "gamma"]).requires_grad_(True)
+        out = ops.residual_gate(x, a, gamma)
+        out.backward(G_(z[p + "g"]))
+        assert_close(out.cpu(), z[p + "out"], 1e-6)
+        assert_close(x.grad.cpu(), z[p + "dx"], 1e-6)
+        assert_close(a.grad.cpu(), z[p + "da"], 1e-5)
+        assert_close(gamma.grad.cpu(), z[p + "dgamma"], 1e-5)     # x^2 g, as the reference codes it
+
+
+def test_residual_gate_large_vs_oracle():
+    from locate_amd import ops
+    from oracle import locate_oracle as O
+    torch.manual_seed(5)
+    for shape, bc in (((64, 48, 64, 64), False), ((64, 192, 16, 16), True), ((8, 512, 1, 1), False)):
+        x = torch.randn(shape)
+        a = torch.randn(shape[0], shape[1], 1, 1) if bc else torch.randn(shape)
+        gamma = torch.tensor([[3.0]])
+        g = torch.randn(shape)
+        xr, ar, gr = (t.clone().requires_grad_(True) for t in (x, a, gamma))
+        ref = O.residual_gate(xr, ar.expand_as(xr), gr)
+        ref.backward(g)
+        xg, ag, gg = (t.to(dev()).requires_grad_(True) for t in (x, a, gamma))
+        out = ops.residual_gate(xg, ag, gg)
+        out.backward(g.to(dev()))
+        assert_close(out.cpu(), ref, 1e-6)
+        assert_close(xg.grad.cpu(), xr.grad, 1e-6)
+        assert_close(ag.grad.cpu(), ar.grad, 2e-5)
+        assert_close(gg.grad.cpu(), gr.grad, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ G4
+def _sn_inner(name):
+    nn = torch.nn
+    return {
+        "conv5s2": lambda: nn.Conv2d(4, 6, 5, stride=2, padding=2, bias=False),
+        "conv3": lambda: nn.Conv2d(5, 3, 3, stride=1, padding=1, bias=False),
+        "conv1x1b": lambda: nn.Conv2d(4, 7, 1),
+        "convT4s2": lambda: nn.ConvTranspose2d(6, 6, 4, stride=2, padding=1, bias=False),
+        "convT1x1": lambda: nn.ConvTranspose2d(6, 3, 1, bias=False),
+        "conv1d": lambda: nn.Conv1d(8, 8, 1, bias=False),
+        "convS1": lambda: nn.Conv2d(8, 2, (4, 1), bias=False),
+        "conv1S": lambda: nn.Conv2d(2, 2, (1, 4), bias=False),
+        "linear": lambda: nn.Linear(10, 6),
+    }[name]()
+
+
+SN_NAMES = ["conv5s2", "conv3", "conv1x1b", "convT4s2", "convT1x1", "conv1d", "convS1", "conv1S", "linear"]
+
+
+@pytest.mark.parametrize("name", SN_NAMES)
+@pytest.mark.parametrize("uvg", [False, True])
+def test_spectral_norm_layers_golden(name, uvg):
+    """Three forwards then ONE backward (the D-step pattern): outputs, u/v state after every forward, dx, dW_bar,
+    dbias and - once u, v are trainable (main.py:172) - du, dv."""
+    from locate_amd import SpectralNorm
+    z = load_golden("g4_spectral_norm")
+    tag = name + ("_uvg" if uvg else "")
+    mod = SpectralNorm(_sn_inner(name))
+    mod.load_state_dict(sub(z, tag + "/sd0/"))
+    mod = mod.to(dev())
+    if uvg:
+        mod.requires_grad_(True)
+    x = G_(z[tag + "/x"]).requires_grad_(True)
+    outs = []
+    for k in range(3):
+        y = mod(x)
+        outs.append(y)
+        assert_close(y.cpu(), z[tag + "/y%d" % k], 2e-5, "y%d" % k)
+        assert_close(mod.module.weight_u.cpu(), z[tag + "/u%d" % k], 1e-5, "u%d" % k)
+        assert_close(mod.module.weight_v.cpu(), z[tag + "/v%d" % k], 1e-5, "v%d" % k)
+    sum((o * G_(z[tag + "/g%d" % k])).sum() for k, o in enumerate(outs)).backward()
+    assert_close(x.grad.cpu(), z[tag + "/dx"], 3e-5, "dx")
+    want = sub(z, tag + "/grad/")
+    got = {k: p.grad.cpu() for k, p in mod.named_parameters() if p.grad is not None}
+    assert set(got) == set(want), set(got) ^ set(want)
+    for k in want:
+        assert_close(got[k], want[k], 1e-4, k)
+
+
+def test_batched_spectral_norm_equals_per_layer():
+    from locate_amd import Discriminator, NetConfig
+    cfg = NetConfig(image_size=32, base_feature_factor=1)
+    torch.manual_seed(4)
+    D1 = Discriminator(cfg).to(dev())
+    D2 = Discriminator(cfg).to(dev())
+    D2.load_state_dict(D1.state_dict())
+    D2.batched_spectral_norm = True
+    x = torch.randn(4, 3, 32, 32, device=dev())
+    for _ in range(2):
+        y1, y2 = D1(x), D2(x)
+    assert_close(y2.cpu(), y1.cpu(), 1e-6)
+    for (k, a), (_, b) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert_close(b.cpu(), a.cpu(), 1e-6, k)
+    y1.sum().backward()
+    y2.sum().backward()
+    for (k, a), (_, b) in zip(D1.named_parameters(), D2.named_parameters()):
+        if a.grad is not None:
+            assert_close(b.grad.cpu(), a.grad.cpu(), 1e-5, k)
+
+
+# ---------------------------------------------------------------------- dense contractions vs torch CPU
+CONV_CASES = [
+    # kind, Cin, Cout, k, stride, pad, B, H, W
+    ("conv", 3, 3, 5, 2, 2, 4, 16, 16),       # D stem conv_0 (M = 3)
+    ("conv", 32, 32, 5, 2, 2, 3, 12, 12),
+    ("conv", 64, 64, 5, 2, 2, 2, 9, 7),       # odd sizes
+    ("conv", 48, 48, 3, 1, 1, 2, 10, 10),     # G head conv_0
+    ("conv", 48, 3, 1, 1, 0, 2, 16, 16),      # G head conv_1 (M = 3)
+    ("conv", 512, 1, 1, 1, 0, 8, 1, 1),       # D head conv_1 (M = 1, N = 8)
+    ("conv", 100, 200, 1, 1, 0, 5, 6, 6),     # M = 200 (two 128 tiles, ragged), K = 100 (ragged K)
+    ("convT", 64, 64, 4, 2, 1, 3, 2, 2),      # G block 0
+    ("convT", 96, 96, 4, 2, 1, 2, 8, 8),      # BM = 96 tile
+    ("convT", 192, 192, 4, 2, 1, 1, 5, 3),    # odd sizes, BM = 96 x 2
+    ("convT", 130, 130, 4, 2, 1, 1, 4, 4),    # ragged M
+    ("convT", 96, 48, 1, 1, 0, 2, 8, 8),      # transposed 1x1 (weights [C_in, C_out, 1, 1])
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,B,H,W", CONV_CASES)
+def test_conv_igemm_vs_cpu(kind, cin, cout, k, s, p, B, H, W):
+    """Forward, data gradient and weight gradient of the implicit-GEMM kernels against ATen CPU convs, through
+    the SpectralNorm module (so 1/sigma folding and the SN backward are covered too)."""
+    from locate_amd import SpectralNorm
+    from oracle import locate_oracle as O
+    torch.manual_seed(cin * 1000 + cout + k)
+    nn = torch.nn
+    inner = (nn.Conv2d if kind == "conv" else nn.ConvTranspose2d)(cin, cout, k, stride=s, padding=p, bias=False)
+    mod = SpectralNorm(inner)
+    sd = {kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(B, cin, H, W)
+    P = O.make_params(sd)
+    xr = x.clone().requires_grad_(True)
+    w = O.sn_weight(P, "module.")
+    yr = F.conv2d(xr, w, None, s, p) if kind == "conv" else F.conv_transpose2d(xr, w, None, s, p)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    mod = mod.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    yg = mod(xg)
+    yg.backward(g.to(dev()))
+    assert_close(yg.cpu(), yr, 2e-5, "y")
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
+    assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
+    assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
+
+
+def test_conv_on_channel_slice_view():
+    """Batch-strided inputs (a channel slice of a bigger NCHW tensor) are consumed in place."""
+    from locate_amd import SpectralNorm
+    torch.manual_seed(8)
+    mod = SpectralNorm(torch.nn.Conv2d(6, 10, 1))
+    mod2 = SpectralNorm(torch.nn.Conv2d(6, 10, 1))
+    mod2.load_state_dict(mod.state_dict())
+    mod, mod2 = mod.to(dev()), mod2.to(dev())
+    big = torch.randn(3, 16, 5, 5, device=dev())
+    view = big[:, 4:10]
+    assert not view.is_contiguous()
+    y1 = mod(view)
+    y2 = mod2(view.contiguous())
+    assert_close(y1.cpu(), y2.cpu(), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ G5
+def test_indexing_bit_exact_and_resampling():
+    from locate_amd import ops
+    z = load_golden("g5_indexing")
+    for r in (4, 2):
+        x = G_(z["fpool%d_x" % r]).requires_grad_(True)
+        y = ops.feature_pool(x, r)
+        y.backward(G_(z["fpool%d_g" % r]))
+        if r == 4:      # C_in / C_out = 2: the only ratio in the architecture -> bit exact
+            assert torch.equal(y.cpu(), T(z["fpool%d_y" % r]))
+            assert torch.equal(x.grad.cpu(), T(z["fpool%d_dx" % r]))
+        else:
+            assert_close(y.cpu(), z["fpool%d_y" % r], 2e-7)
+            assert torch.equal(x.grad.cpu(), T(z["fpool%d_dx" % r]))
+    x = G_(z["up_x"]).requires_grad_(True)
+    y = ops.upsample2x(x)
+    y.backward(G_(z["up_g"]))
+    assert_close(y.cpu(), z["up_y"], 1e-6)
+    assert_close(x.grad.cpu(), z["up_dx"], 1e-6)
+    x = G_(z["pool_x"]).requires_grad_(True)
+    y = ops.avgpool2(x)
+    y.backward(G_(z["pool_g"]))
+    assert_close(y.cpu(), z["pool_y"], 1e-6)
+    assert_close(x.grad.cpu(), z["pool_dx"], 1e-6)
+    from locate_amd import Expand, ResModule
+    e = Expand(-1, 5, 4, 4)
+    t = G_(z["expand_x"]).requires_grad_(True)
+    out = e(t)
+    assert torch.equal(out.cpu(), T(z["expand_y"]))
+    out.backward(G_(z["expand_g"]))
+    assert_close(t.grad.cpu(), z["expand_dx"], 1e-6)
+
+
+def test_cat_channels():
+    from locate_amd import ops
+    torch.manual_seed(2)
+    a = torch.randn(3, 4, 5, 5, device=dev(), requires_grad=True)
+    b = torch.randn(3, 7, 5, 5, device=dev(), requires_grad=True)
+    out = ops.cat_channels(a, b)
+    assert torch.equal(out, torch.cat([a, b], 1))
+    g = torch.randn_like(out)
+    out.backward(g)
+    assert torch.equal(a.grad, g[:, :4]) and torch.equal(b.grad, g[:, 4:])
+
+
+@pytest.mark.parametrize("name,args", [("scale_up_pool", (8, 4, 2, True)), ("scale_up_cat", (4, 12, 2, True)),
+                                       ("scale_down_cat", (4, 8, 2, False)), ("scale_down_same", (6, 6, 2, False))])
+def test_scale_compositions_golden(name, args):
+    from locate_amd import Scale
+    z = load_golden("g5_indexing")
+    layer = Scale(*args)
+    if isinstance(layer, torch.nn.Module):
+        layer.load_state_dict(sub(z, name + "/sd0/"))
+        layer = layer.to(dev())
+    x = G_(z[name + "/x"]).requires_grad_(True)
+    y = layer(x)
+    y.backward(G_(z[name + "/g"]))
+    assert_close(y.cpu(), z[name + "/y"], 1e-5)
+    assert_close(x.grad.cpu(), z[name + "/dx"], 2e-5)
+    if isinstance(layer, torch.nn.Module):
+        for k, v in sub(z, name + "/grad/").items():
+            assert_close(dict(layer.named_parameters())[k].grad.cpu(), v, 5e-5, k)
+        for k, v in sub(z, name + "/sd1/").items():
+            assert_close(layer.state_dict()[k].cpu(), v, 1e-5, k)
+
+
+# ------------------------------------------------------------------------------------------------ softmax
+@pytest.mark.parametrize("rows,n", [(7, 3), (64 * 16, 64), (96, 256), (33, 1000), (64 * 48, 4096), (5, 65536), (64, 192)])
+def test_softmax_rows(rows, n):
+    from locate_amd import ops
+    torch.manual_seed(rows + n)
+    x = torch.randn(rows, n) * 3
+    g = torch.randn(rows, n)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.softmax(xr, -1)
+    yr.backward(g)
+    xg = x.to(dev()).requires_grad_(True)
+    yg = ops.softmax_lastdim(xg)
+    yg.backward(g.to(dev()))
+    assert_close(yg.cpu(), yr, 2e-6)
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ G6
+def test_attention_layers_and_linear_golden():
+    from locate_amd import LinearModule, NetConfig, SelfAttention, feature_attention
+    z = load_golden("g6_attention")
+    cfg = NetConfig()
+    for name, mod in (("fa", feature_attention(8, 16, cfg=cfg)), ("sa", SelfAttention(16))):
+        mod.load_state_dict(sub(z, name + "/sd0/"))
+        mod = mod.to(dev())
+        x = G_(z[name + "/x"]).requires_grad_(True)
+        y = mod(x)
+        y.backward(G_(z[name + "/g"]))
+        assert_close(y.cpu(), z[name + "/y"], 1e-5, name)
+        assert_close(x.grad.cpu(), z[name + "/dx"], 5e-5, name + " dx")
+        params = dict(mod.named_parameters())
+        for k, v in sub(z, name + "/grad/").items():
+            assert_close(params[k].grad.cpu(), v, 2e-4, name + k)
+        for k, v in sub(z, name + "/sd1/").items():
+            assert_close(mod.state_dict()[k].cpu(), v, 1e-5, k)
+    lm = LinearModule(12, 7)
+    lm.load_state_dict(sub(z, "lin/sd0/"))
+    lm = lm.to(dev())
+    x = G_(z["lin/x"]).requires_grad_(True)
+    act, pre = lm(x)
+    ((act * G_(z["lin/g_act"])).sum() + (pre * G_(z["lin/g_pre"])).sum()).backward()
+    assert_close(act.cpu(), z["lin/act"], 1e-5)
+    assert_close(pre.cpu(), z["lin/pre"], 1e-5)
+    assert_close(x.grad.cpu(), z["lin/dx"], 3e-5)
+    params = dict(lm.named_parameters())
+    for k, v in sub(z, "lin/grad/").items():
+        assert_close(params[k].grad.cpu(), v, 1e-4, k)
+
+
+# ------------------------------------------------------------------------------------------------ G7
+@pytest.mark.parametrize("name,size,cin,cout,idx,transposed", [
+    ("up", 8, 16, 8, 0, True), ("up_na", 4, 8, 8, 1, True), ("down", 8, 8, 16, 0, False), ("down_na", 4, 16, 16, 1, False)])
+def test_blocks_golden(name, size, cin, cout, idx, transposed):
+    from locate_amd import Block, NetConfig
+    z = load_golden("g7_blocks")
+    blk = Block(size, cin, cout, 2, transposed, idx, cfg=NetConfig())
+    blk.load_state_dict(sub(z, name + "/sd0/"))
+    blk = blk.to(dev())
+    x = G_(z[name + "/x"]).requires_grad_(True)
+    scales = None
+    if transposed:
+        scales = [G_(z[name + "/scale%d" % i]).requires_grad_(True) for i in range(3) if name + "/scale%d" % i in z.files]
+    y = blk(x, scales)
+    y.backward(G_(z[name + "/g"]))
+    assert_close(y.cpu(), z[name + "/y"], 3e-5, "y")
+    assert_close(x.grad.cpu(), z[name + "/dx"], 2e-4, "dx")
+    if scales:
+        for i, s in enumerate(scales):
+            assert_close(s.grad.cpu(), z[name + "/dscale%d" % i], 2e-4, "dscale%d" % i)
+    want = sub(z, name + "/grad/")
+    got = {k: p.grad.cpu() for k, p in blk.named_parameters() if p.grad is not None}
+    assert set(got) == set(want), set(got) ^ set(want)
+    for k, v in want.items():
+        assert_close(got[k], v, 3e-4, k)
+    for k, v in sub(z, name + "/sd1/").items():
+        assert_close(blk.state_dict()[k].cpu(), v, 1e-5, k)
+
+
+# ------------------------------------------------------------------------------------------------ G9
+def test_nadam_golden():
+    from locate_amd import Nadam
+    z = load_golden("g9_nadam")
+    ps = [torch.nn.Parameter(G_(z["p%d_0" % i]).clone()) for i in range(3)]
+    opt = Nadam(ps, lr=float(z["lr"]), betas=tuple(float(b) for b in z["betas"]))
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            key = "g%d_%d" % (i, step)
+            p.grad = G_(z[key]).clone() if key in z.files else None
+        opt.step()
+        for i, p in enumerate(ps):
+            assert_close(p.detach().cpu(), z["p%d_%d" % (i, step)], 2e-6, "p%d step %d" % (i, step))
+
+
+def test_loss_kernels():
+    from locate_amd.train import d_loss, g_loss
+    from oracle import locate_oracle as O
+    torch.manual_seed(1)
+    for B in (8, 64, 300):
+        t, f, a = (torch.randn(B) * 2 for _ in range(3))
+        t[0], f[0] = 1.0, -1.0          # hinge arguments exactly 0: clamp passes the gradient there
+        tr, fr, ar = (v.clone().requires_grad_(True) for v in (t, f, a))
+        d_err = (O.hinge(tr) + O.hinge(-fr)).mean()       # main.py:150-155: d_gen = -D(generated)
+        pen = O.consistency_penalty(tr, ar)
+        (d_err + pen).backward()
+        losses, gt, gf, ga = d_loss(t.to(dev()), f.to(dev()), a.to(dev()))
+        assert_close(losses.cpu(), torch.stack([d_err, pen, d_err + pen]).detach(), 2e-6)
+        assert_close(gt.cpu(), tr.grad, 1e-5)
+        assert_close(gf.cpu(), fr.grad, 1e-6)
+        assert_close(ga.cpu(), ar.grad, 1e-5)
+        fr2 = f.clone().requires_grad_(True)
+        ge = O.hinge(fr2).mean()
+        ge.backward()
+        loss, g = g_loss(f.to(dev()))
+        assert_close(loss.cpu(), ge.detach().reshape(1), 2e-6)
+        assert_close(g.cpu(), fr2.grad, 1e-6)

@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared symbol, the module
+tree has the reference's state_dict layout, and seeded construction reproduces the reference's RNG draw order
+(tests/golden/g10_init_*.npz, generated from the reference by oracle/gen_golden.py)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+import locate_amd
+from locate_amd import Discriminator, Generator, NetConfig, get_model, parameter_count
+from locate_amd._lib import PROTOTYPES, LocateError, lib
+from locate_amd.models import discriminator_features, generator_features
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    header = open(os.path.join(ROOT, "include", "locate_hip.h")).read()
+    declared = set(re.findall(r"\b(locate_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(PROTOTYPES), declared ^ set(PROTOTYPES)
+    handle = lib()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.locate_abi_version() == 1
+    assert handle.locate_sn_table_record_bytes() == 80
+    assert handle.locate_nadam_tensor_record_bytes() == 48
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without an MI355X: CPU tensors are rejected, not silently computed."""
+    from locate_amd import ops
+    with pytest.raises(TypeError):
+        ops.root_tanh(torch.randn(8))
+    if not torch.cuda.is_available():
+        from locate_amd._lib import require_gpu
+        with pytest.raises(LocateError):
+            require_gpu()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "locate_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the CPU oracle", ""), f
+
+
+def test_feature_lists():
+    assert generator_features(NetConfig(64)) == [64, 768, 384, 192, 96, 48]
+    assert discriminator_features(NetConfig(64)) == [32, 64, 128, 256, 512, 512]
+    assert generator_features(NetConfig(128)) == [128, 1536, 768, 384, 192, 96, 48]
+    assert discriminator_features(NetConfig(256)) == [32, 64, 128, 256, 512, 1024, 2048, 2048]
+    assert generator_features(NetConfig(32, 1)) == [32, 48, 24, 12, 4]
+
+
+@pytest.mark.parametrize("which,size,bff", [("tiny32", 32, 1), ("full32", 32, 8), ("full64", 64, 8)])
+def test_seeded_construction_matches_reference(which, size, bff):
+    z = load_golden("g10_init_" + which)
+    cfg = NetConfig(image_size=size, base_feature_factor=bff)
+    torch.manual_seed(cfg.seed)
+    G, _ = get_model(Generator(cfg), cfg.glr, "cpu")
+    D, _ = get_model(Discriminator(cfg), cfg.dlr, "cpu")
+    assert G.g_in == int(z["G/g_in"])
+    for tag, net in (("G", G), ("D", D)):
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(z[tag + "/keys"])
+        assert [str(tuple(v.shape)) for v in sd.values()] == list(z[tag + "/shapes"])
+        np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], z[tag + "/sum"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose([float(v.double().abs().sum()) for v in sd.values()], z[tag + "/abssum"], rtol=0, atol=1e-9)
+        assert [bool(p.requires_grad) for _, p in net.named_parameters()] == list(z[tag + "/requires_grad"])
+        assert parameter_count(net) == int(z[tag + "/param_count"])
+    assert float(G.noise.double().sum()) == pytest.approx(float(z["G/noise_sum"]), abs=1e-9)
+    assert "noise" not in G.state_dict()
+    np.testing.assert_array_equal(torch.randn(4).numpy(), z["after_rng"])   # same RNG position afterwards
+
+
+def test_requires_grad_toggle_makes_uv_trainable():
+    cfg = NetConfig(image_size=32, base_feature_factor=1)
+    D = Discriminator(cfg)
+    before = parameter_count(D)
+    D.requires_grad_(False)
+    D.requires_grad_(True)          # main.py:161,172
+    z = load_golden("g8_tiny_e2e")
+    assert before == int(z["meta/d_param_count"])
+    assert parameter_count(D) == int(z["meta/d_param_count_after"])
+
+
+def test_noise_follows_module_moves():
+    G = Generator(NetConfig(image_size=32, base_feature_factor=1))
+    G = G.double()
+    assert G.noise.dtype == torch.float64
