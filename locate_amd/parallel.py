@@ -57,20 +57,25 @@ class GradAllReducer:
         self._active = False
         self._side = None
         self._hooks = []
-        if self.world > 1:
-            for i, p in enumerate(self.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self._hooked = set()
 
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._hooked = set()
 
     # ------------------------------------------------------------------------------------------
     def begin(self):
         """Call right before backward()."""
         if self.world == 1:
             return
+        # hooks are (re)registered lazily: a tensor can only carry one once it requires grad, and the
+        # discriminator's u/v only start to after the first G-step (reference main.py:172)
+        for i, p in enumerate(self.params):
+            if p.requires_grad and i not in self._hooked:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                self._hooked.add(i)
         self._ready = [0] * len(self.buckets)
         self._seen = set()
         self._launched = [False] * len(self.buckets)

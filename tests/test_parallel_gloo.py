@@ -1,0 +1,100 @@
+"""Data-parallel gradient averaging (locate_amd/parallel.py) with world_size 2 on CPU over gloo.
+Parity statement under test: after finish(), every rank's .grad equals the MEAN of the gradients each rank
+computed on its own shard; parameters without a gradient stay None; replicas start identical after broadcast."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, bucket_bytes, overlap, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from locate_amd.parallel import GradAllReducer, broadcast_module_state
+        torch.manual_seed(100 + rank)            # different initial weights per rank on purpose
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        unused = torch.nn.Parameter(torch.randn(4))          # like G's unused i_norm.weight: grad stays None
+        frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)   # like D's u/v before main.py:172
+        extra = torch.randn(1, 3, 2, 2)                      # like Generator.noise
+        broadcast_module_state(net, 0, extra_tensors=[extra, unused.data, frozen.data])
+        params = list(net.parameters()) + [unused, frozen]
+        red = GradAllReducer(params, bucket_bytes=bucket_bytes, overlap=overlap)
+        torch.manual_seed(7)                                  # same data stream on both ranks, shard by rank
+        x = torch.randn(8, 6)
+        shard = x[rank * 4:(rank + 1) * 4]
+        results = []
+        for it in range(2):
+            for p in params:
+                p.grad = None
+            loss = net(shard).pow(2).mean() * (it + 1)
+            red.begin()
+            loss.backward()
+            red.finish()
+            results.append([None if p.grad is None else p.grad.clone() for p in params])
+        # single-process truth: mean over the two shards' gradients
+        truth = []
+        for it in range(2):
+            acc = None
+            for r in range(world):
+                for p in params:
+                    p.grad = None
+                (net(x[r * 4:(r + 1) * 4]).pow(2).mean() * (it + 1)).backward()
+                g = [None if p.grad is None else p.grad.clone() for p in params]
+                acc = g if acc is None else [None if a is None else a + b for a, b in zip(acc, g)]
+            truth.append([None if a is None else a / world for a in acc])
+        ok = True
+        for got, want in zip(results, truth):
+            for a, b in zip(got, want):
+                if (a is None) != (b is None):
+                    ok = False
+                elif a is not None and not torch.allclose(a, b, rtol=1e-6, atol=1e-7):
+                    ok = False
+        w0 = [p.detach().clone() for p in net.parameters()] + [extra]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [t.tolist() for t in w0])
+        same_weights = gathered[0] == gathered[1]
+        q.put((rank, ok, same_weights, len(red.buckets)))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("bucket_bytes,overlap", [(32 << 20, True), (64, True), (64, False)])
+def test_grad_allreduce_world2(bucket_bytes, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, same, info in res:
+        assert ok and same, (rank, info)
+    if bucket_bytes == 64:
+        assert res[0][3] > 1        # several buckets were exercised
+
+
+def test_single_process_is_a_no_op():
+    from locate_amd.parallel import GradAllReducer
+    p = torch.nn.Parameter(torch.randn(3))
+    red = GradAllReducer([p])
+    red.begin()
+    (p * 2).sum().backward()
+    red.finish()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
