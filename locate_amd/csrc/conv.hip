@@ -109,6 +109,9 @@ struct IgParams {
     int B, C, H, W;      // gathered tensor: C = reduction channels
     int M, OH, OW;       // produced tensor
     int istride, ostep, nphase;
+    int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab` (dense [ksplit][B, M, OH, OW])
+    float* slab;
+    long long slab_stride;
     IgPhase ph[4];
 };
 
@@ -126,7 +129,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[2][IG_BK][BN];
     __shared__ int doff_s[IG_MAXT];
 
-    const IgPhase& ph = p.ph[blockIdx.z];
+    const int zphase = blockIdx.z / p.ksplit, zsplit = blockIdx.z - zphase * p.ksplit;
+    const IgPhase& ph = p.ph[zphase];
     const int N = p.B * ph.QH * ph.QW;
     const int n0 = blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
@@ -211,14 +215,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = breg[j];
     };
 
-    const int nsteps = ph.Kpad / IG_BK;
-    load_tiles(0);
-    store_tiles(0);
+    const int total_steps = ph.Kpad / IG_BK;
+    const int per_split = (total_steps + p.ksplit - 1) / p.ksplit;
+    const int step0 = zsplit * per_split;
+    int nsteps = total_steps - step0;
+    if (nsteps > per_split) nsteps = per_split;
+    if (nsteps < 0) nsteps = 0;
+    if (nsteps > 0) {
+        load_tiles(step0 * IG_BK);
+        store_tiles(0);
+    }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_tiles((s + 1) * IG_BK);
+        if (s + 1 < nsteps) load_tiles((step0 + s + 1) * IG_BK);
 #pragma unroll
         for (int k2 = 0; k2 < IG_BK / 2; ++k2) {
             float a[TM], b[TN];
@@ -244,7 +255,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         const int qhw = ph.QH * ph.QW;
         const int b = nj / qhw, q = nj - b * qhw;
         const int qy = q / ph.QW, qx = q - qy * ph.QW;
-        float* optr = p.out + (long long)b * p.out_bs + (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
+        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
+        const bool split = p.ksplit > 1;
+        float* optr = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
+                            : p.out + (long long)b * p.out_bs + pix;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -252,11 +266,26 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[m];
+                    if (p.bias && !split) v += p.bias[m];
                     optr[(long long)m * plane] = v;
                 }
             }
         }
+    }
+}
+
+// out[b, m, :] = bias[m] + sum_z slab[z][b, m, :]
+__global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                                const float* __restrict__ bias, int B, int M, int plane,
+                                                                long long out_bs, long long slab_stride, int ksplit) {
+    const long long per_b = (long long)M * plane;
+    const long long total = (long long)B * per_b;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long b = i / per_b, r = i - b * per_b;
+        float acc = bias ? bias[(int)(r / plane)] : 0.0f;
+        for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
+        out[b * out_bs + r] = acc;
     }
 }
 
@@ -270,14 +299,44 @@ static int pick_bm(int M) {
     return best;
 }
 
-static int launch_igemm(const IgParams& p, int nmax, hipStream_t st, const char* who) {
+// Split K over extra blocks when the (M, N) tiling alone cannot fill 256 CUs (deep discriminator layers and the
+// first generator stages: N = B*OH*OW is only 64 ... 1024 there while K = C*KH*KW is up to 12 800).
+static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
+    const int bm = pick_bm(M);
+    const long long tiles = (long long)((nmax + 127) / 128) * ((M + bm - 1) / bm) * nphase;
+    if (tiles >= 384) return 1;
+    const int steps = min_kpad / IG_BK;
+    long long want = (768 + tiles - 1) / tiles;
+    const int max_split = steps / 8 > 0 ? steps / 8 : 1;      // at least 8 K steps (128 reduction elements) per block
+    if (want > max_split) want = max_split;
+    if (want > 64) want = 64;
+    return want < 1 ? 1 : (int)want;
+}
+
+static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, const char* who) {
     const int bm = pick_bm(p.M);
-    dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase);
+    int min_kpad = 1 << 30;
+    for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
+    p.ksplit = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
+    p.slab = static_cast<float*>(slab_ws);
+    p.slab_stride = (long long)p.B * p.M * p.OH * p.OW;
+    if (p.ksplit > 1) {
+        for (int i = 0; i < p.nphase; ++i)   // phases with fewer K steps than splits would leave slab tiles unwritten
+            if (p.ph[i].Kpad / IG_BK < p.ksplit) p.ksplit = p.ph[i].Kpad / IG_BK;
+        if (p.ksplit < 1) p.ksplit = 1;
+    }
+    dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
     if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
     else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
     else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
     else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     LOCATE_LAUNCH_CHECK(who);
+    if (p.ksplit > 1) {
+        const long long total = p.slab_stride;
+        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.B, p.M, p.OH * p.OW, p.out_bs,
+                                                                         p.slab_stride, p.ksplit);
+        LOCATE_LAUNCH_CHECK(who);
+    }
     return LOCATE_OK;
 }
 
@@ -298,25 +357,27 @@ static ConvGeom make_geom(const int* g) {
 }
 
 // geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
-LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) {
-    const ConvGeom g = make_geom(geom);
-    return (size_t)round_up(g.C * g.KH * g.KW, IG_BK) * round_up(g.M, 32) * sizeof(float);
+//
+// Workspace layout of locate_conv_fwd / locate_conv_dgrad: [ packed weight panels | split-K slabs ].
+// The same routine runs "dry" (no launches) to size the workspace, so sizing and execution cannot disagree.
+static size_t slab_floats(const IgParams& p, int nmax) {
+    int min_kpad = 1 << 30;
+    for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
+    int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
+    if (ks > min_kpad / IG_BK) ks = min_kpad / IG_BK;
+    return ks > 1 ? (size_t)ks * p.B * p.M * p.OH * p.OW : 0;
 }
 
-// y[b, m, oh, ow] = bias[m] + inv_scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]
-// x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
-LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
-                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
-    const ConvGeom g = make_geom(geom);
-    if (int e = geom_check(g, "locate_conv_fwd")) return e;
-    LOCATE_REQUIRE(workspace && x && w && y, "locate_conv_fwd: null pointer");
-    hipStream_t st = as_stream(stream);
+static int run_conv_fwd(const ConvGeom& g, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
+                        const float* bias, float* y, int64_t y_bs, float* ws, hipStream_t st, bool dry, size_t* ws_floats) {
     PackArgs pa;
-    pa.w = w; pa.inv_scale = inv_scale; pa.out = static_cast<float*>(workspace);
+    pa.w = w; pa.inv_scale = inv_scale; pa.out = ws;
     pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
     pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
     pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_BK); pa.ld = round_up(g.M, 32);
-    if (int e = launch_pack(pa, st, "locate_conv_fwd(pack)")) return e;
+    const size_t pack_floats = (size_t)pa.Kpad * pa.ld;
+    if (!dry)
+        if (int e = launch_pack(pa, st, "locate_conv_fwd(pack)")) return e;
 
     IgParams p;
     p.in = x; p.out = y; p.bias = bias; p.in_bs = x_bs; p.out_bs = y_bs;
@@ -330,7 +391,27 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
             ph.dy[kh * g.KW + kw] = (signed char)(kh - g.pad_h);
             ph.dx[kh * g.KW + kw] = (signed char)(kw - g.pad_w);
         }
-    return launch_igemm(p, g.B * g.OH * g.OW, st, "locate_conv_fwd(igemm)");
+    const int nmax = g.B * g.OH * g.OW;
+    if (ws_floats) *ws_floats = pack_floats + slab_floats(p, nmax);
+    if (dry) return LOCATE_OK;
+    return launch_igemm(p, nmax, ws + pack_floats, st, "locate_conv_fwd(igemm)");
+}
+
+LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) {
+    size_t n = 0;
+    run_conv_fwd(make_geom(geom), nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, true, &n);
+    return n * sizeof(float);
+}
+
+// y[b, m, oh, ow] = bias[m] + inv_scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]
+// x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
+LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
+                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_fwd")) return e;
+    LOCATE_REQUIRE(workspace && x && w && y, "locate_conv_fwd: null pointer");
+    return run_conv_fwd(g, x, x_bs, w, inv_scale, bias, y, y_bs, static_cast<float*>(workspace), as_stream(stream), false,
+                        nullptr);
 }
 
 static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int* T) {
@@ -339,33 +420,13 @@ static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int*
     *T = *k0 < K ? (K - *k0 + s - 1) / s : 0;
 }
 
-LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) {
-    const ConvGeom g = make_geom(geom);
-    size_t total = 0;
-    for (int py = 0; py < g.stride; ++py)
-        for (int px = 0; px < g.stride; ++px) {
-            int kh0, dy0, TH, kw0, dx0, TW;
-            phase_taps(py, g.pad_h, g.KH, g.stride, &kh0, &dy0, &TH);
-            phase_taps(px, g.pad_w, g.KW, g.stride, &kw0, &dx0, &TW);
-            total += (size_t)round_up(g.M * TH * TW, IG_BK) * round_up(g.C, 32);
-        }
-    return total * sizeof(float);
-}
-
-// gx[b, c, i, j] = bias[c] + inv_scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
-// (data adjoint of R; it is also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]).
-// Every element of gx [B, C, H, W] is written.
-LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
-                                 const float* bias, float* gx, int64_t gx_bs, void* workspace, void* stream) {
-    const ConvGeom g = make_geom(geom);
-    if (int e = geom_check(g, "locate_conv_dgrad")) return e;
-    LOCATE_REQUIRE(workspace && gy && w && gx, "locate_conv_dgrad: null pointer");
-    hipStream_t st = as_stream(stream);
+static int run_conv_dgrad(const ConvGeom& g, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
+                          const float* bias, float* gx, int64_t gx_bs, float* ws, hipStream_t st, bool dry, size_t* ws_floats) {
     IgParams p;
     p.in = gy; p.out = gx; p.bias = bias; p.in_bs = gy_bs; p.out_bs = gx_bs;
     p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
     p.istride = 1; p.ostep = g.stride; p.nphase = 0;
-    float* wsp = static_cast<float*>(workspace);
+    size_t pack_floats = 0;
     int nmax = 0;
     for (int py = 0; py < g.stride; ++py)
         for (int px = 0; px < g.stride; ++px) {
@@ -377,12 +438,13 @@ LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs
             if (QH == 0 || QW == 0) continue;
             IgPhase& ph = p.ph[p.nphase++];
             PackArgs pa;
-            pa.w = w; pa.inv_scale = inv_scale; pa.out = wsp;
+            pa.w = w; pa.inv_scale = inv_scale; pa.out = ws + pack_floats;
             pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
             pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
             pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_BK); pa.ld = round_up(g.C, 32);
-            if (int e = launch_pack(pa, st, "locate_conv_dgrad(pack)")) return e;
-            wsp += (size_t)pa.Kpad * pa.ld;
+            if (!dry)
+                if (int e = launch_pack(pa, st, "locate_conv_dgrad(pack)")) return e;
+            pack_floats += (size_t)pa.Kpad * pa.ld;
             ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
             ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
             for (int th = 0; th < TH; ++th)
@@ -393,8 +455,28 @@ LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs
             const int nph = g.B * QH * QW;
             if (nph > nmax) nmax = nph;
         }
+    if (ws_floats) *ws_floats = pack_floats + (p.nphase > 0 ? slab_floats(p, nmax) : 0);
+    if (dry) return LOCATE_OK;
     LOCATE_REQUIRE(p.nphase > 0, "locate_conv_dgrad: empty output");
-    return launch_igemm(p, nmax, st, "locate_conv_dgrad(igemm)");
+    return launch_igemm(p, nmax, ws + pack_floats, st, "locate_conv_dgrad(igemm)");
+}
+
+LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) {
+    size_t n = 0;
+    run_conv_dgrad(make_geom(geom), nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, true, &n);
+    return n * sizeof(float);
+}
+
+// gx[b, c, i, j] = bias[c] + inv_scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
+// (data adjoint of R; it is also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]).
+// Every element of gx [B, C, H, W] is written.
+LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
+                                 const float* bias, float* gx, int64_t gx_bs, void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_dgrad")) return e;
+    LOCATE_REQUIRE(workspace && gy && w && gx, "locate_conv_dgrad: null pointer");
+    return run_conv_dgrad(g, gy, gy_bs, w, inv_scale, bias, gx, gx_bs, static_cast<float*>(workspace), as_stream(stream), false,
+                          nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,7 +1,12 @@
 """Whole-step hipGraph capture.  One G+D iteration is ~3000 small launches (the reference's Python issues about
-as many ATen calls); replaying them as ONE graph removes the host from the loop - the MI355X-native
-replacement for a tracing compiler.  Everything the step mutates (weights, spectral-norm u/v, Nadam moments and
-schedule counters) lives in device memory at fixed addresses, so replay == one more training iteration."""
+as many ATen calls); replaying them as graphs removes the host from the loop - the MI355X-native replacement
+for a tracing compiler.  Everything the step mutates (weights, spectral-norm u/v, Nadam moments and schedule
+counters) lives in device memory at fixed addresses, so one replay == one more training iteration.
+
+The iteration is captured as FOUR graphs sharing one memory pool (D forward/backward, D Nadam, G
+forward/backward, G Nadam): the optimizer's device tables hold the addresses of the gradient buffers, which
+only exist once the preceding backward has been captured, and building them needs pinned-host staging, which is
+not allowed inside a capture - so they are built eagerly between two captures."""
 import torch
 
 
@@ -20,13 +25,39 @@ class GraphedTrainStep:
                 step(*self.inputs)
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = step(*self.inputs)
+        lat, real_, aug_ = self.inputs
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs = []
+        self.outputs = {}
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                out = fn()
+            self.graphs.append(g)
+            if out:
+                self.outputs.update(out)
+
+        capture(lambda: step.d_forward_backward(lat, real_, aug_))
+        self._prime(step.dis_opt)
+        capture(step.d_optimizer)
+        capture(lambda: step.g_forward_backward(lat))
+        self._prime(step.gen_opt)
+        capture(step.g_optimizer)
+
+    @staticmethod
+    def _prime(opt):
+        """Build the optimizer's device tables for the gradient buffers the captured backward just allocated."""
+        for group in opt.param_groups:
+            plist = [p for p in group["params"] if p.grad is not None]
+            if plist:
+                opt._table(plist)
+        torch.cuda.synchronize()
 
     def replay(self, latent=None, real=None, aug=None):
         for dst, src in zip(self.inputs, (latent, real, aug)):
             if src is not None:
                 dst.copy_(src)
-        self.graph.replay()
+        for g in self.graphs:
+            g.replay()
         return self.outputs

@@ -48,7 +48,8 @@ class TrainStep:
         self.minibatches = minibatches
         self.reducer_g, self.reducer_d = reducer_g, reducer_d
 
-    def d_step(self, latent, real, aug):
+    # ---- the four phases of one iteration (kept separate so that each can be its own hipGraph) --------------
+    def d_forward_backward(self, latent, real, aug):
         gen, dis = self.gen, self.dis
         with torch.no_grad():                      # main.py:146 builds a graph and drops it (.detach()); same values
             generated = gen(latent)
@@ -62,11 +63,13 @@ class TrainStep:
         torch.autograd.backward([d_true, d_fake, d_aug], [g_t.view_as(d_true), g_f.view_as(d_fake), g_a.view_as(d_aug)])  # :156
         if self.reducer_d is not None:
             self.reducer_d.finish()
-        self.dis_opt.step()                        # :159
         return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
                 "d_gen": -d_fake.detach().view(-1), "generated": generated}
 
-    def g_step(self, latent):
+    def d_optimizer(self):
+        self.dis_opt.step()                        # :159
+
+    def g_forward_backward(self, latent):
         gen, dis = self.gen, self.dis
         dis.requires_grad_(False)                  # main.py:161
         try:
@@ -80,10 +83,22 @@ class TrainStep:
                 d_out.backward(g.view_as(d_out))
                 if self.reducer_g is not None:
                     self.reducer_g.finish()
-            self.gen_opt.step()                    # :171
         finally:
-            dis.requires_grad_(True)               # :172 (u, v included)
+            dis.requires_grad_(True)               # :172 (u, v included; the reference does it after GEN_OPTIM.step())
         return {"g_error": loss[0], "fake": fake.detach()}
+
+    def g_optimizer(self):
+        self.gen_opt.step()                        # :171
+
+    def d_step(self, latent, real, aug):
+        out = self.d_forward_backward(latent, real, aug)
+        self.d_optimizer()
+        return out
+
+    def g_step(self, latent):
+        out = self.g_forward_backward(latent)
+        self.g_optimizer()
+        return out
 
     def __call__(self, latent, real, aug):
         out = self.d_step(latent, real, aug)

@@ -136,3 +136,25 @@ def test_config1_full_width_step_vs_reference_record():
             if tag == "D" and (k.endswith("weight_u") or k.endswith("weight_v")):
                 continue   # D's u/v were advanced once more by the G-step's D forward after the record point
             assert abs(float(sd[k].double().norm()) - w) <= 1e-4 * max(w, 1e-6) + 1e-6, (tag, k)
+
+
+def test_graph_replay_equals_eager():
+    """hipGraph replay of the four captured phases must produce the same trajectory as eager launches."""
+    from locate_amd.graph import GraphedTrainStep
+    z = load_golden("g8_tiny_e2e")
+    cfg, G1, D1, step1, dev = _build_tiny(z, True)
+    _, G2, D2, step2, _ = _build_tiny(z, True)
+    lat, real, aug = (T(z["step1/" + k]).to(dev) for k in ("latent", "real", "aug"))
+    runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations + the captured one
+    for _ in range(3):
+        out1 = step1(lat, real, aug)
+    for _ in range(2):                                               # two replays
+        out1 = step1(lat, real, aug)
+        out2 = runner.replay()
+    torch.cuda.synchronize()
+    for k in ("d_error", "g_error", "fake"):
+        assert_close(out2[k].cpu(), out1[k].cpu(), 1e-4, k)
+    for (k, a), (_, b) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert_close(b.cpu(), a.cpu(), 2e-4, "D " + k)
+    for (k, a), (_, b) in zip(G1.state_dict().items(), G2.state_dict().items()):
+        assert_close(b.cpu(), a.cpu(), 2e-4, "G " + k)
