@@ -91,14 +91,17 @@ int locate_sn_weight_bwd(const float* g, const float* w, const float* u, const f
 /* ---- dense contractions as implicit GEMMs on the fp32 MFMA (libs/conv.py:14-20, libs/attention.py:18-46,
  *      libs/scale.py:25-34, libs/linear.py:10).  geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW}
  *      describes the REGULAR convolution R: out[b,m,oh,ow] = sum w[m,c,kh,kw] in[b,c,oh*s-ph+kh,ow*s-pw+kw].
- *      inv_scale (nullable device scalar) multiplies the weights (1/sigma of spectral norm);
- *      *_bs are batch strides in elements. ---- */
+ *      The weight operand is a pre-packed K-major panel (locate_conv_pack_panel; redo only when W changes);
+ *      `scale` (nullable device scalar) multiplies the contraction in the epilogue (1/sigma of spectral norm,
+ *      libs/spectral_norm.py:31-32); *_bs are batch strides in elements; workspace = split-K slabs (may be 0). ---- */
+size_t locate_conv_panel_bytes(const int* geom, int adjoint);
+int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* panel, void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
-int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale, const float* bias,
+int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale, const float* bias,
                     float* y, int64_t y_bs, void* workspace, void* stream);
-/* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]) */
+/* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
-int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale, const float* bias,
+int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale, const float* bias,
                       float* gx, int64_t gx_bs, void* workspace, void* stream);
 /* gw[m,c,kh,kw] = sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction) */
 size_t locate_conv_wgrad_workspace_bytes(const int* geom);

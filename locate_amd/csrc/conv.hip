@@ -14,9 +14,9 @@
 // A stride-s adjoint is decomposed into s*s sub-pixel phases, each a stride-1 gather with its own tap subset
 // (4x4 s2 p1 ConvTranspose = four 2x2 convolutions; 5x5 s2 p2 dgrad = 3x3 + 3x2 + 2x3 + 2x2 taps).
 //
-// The weight operand is re-packed per call into a K-major [Kpad][Mpad] panel (zero padded) with the
-// spectral-norm factor 1/sigma folded in (reference libs/spectral_norm.py:31-32 materialises W_bar/sigma
-// as a separate full-size tensor on every forward; here it only ever exists as the packed panel).
+// The weight operand is re-laid out once per weight update into a K-major [Kpad][Mpad] panel (zero padded);
+// the spectral-norm factor 1/sigma multiplies the accumulator in the epilogue (reference
+// libs/spectral_norm.py:31-32 materialises W_bar/sigma as a separate full-size tensor on every forward).
 //
 // Tiling: 256 threads = 4 waves, block tile BM x 128 (BM in {128, 96, 64, 32}), K step 16, double-buffered
 // LDS with register prefetch of the next K step, one barrier per step.
@@ -53,7 +53,6 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // ---------------------------------------------------------------------------------------------
 struct PackArgs {
     const float* w;       // [M, C, KH, KW]
-    const float* inv_scale;  // device scalar or null
     float* out;           // [Kpad][ld]
     int M, C, KH, KW;
     int mode;             // 0: rows k=(c,kh,kw), cols m          (R forward)
@@ -63,7 +62,6 @@ struct PackArgs {
 };
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
-    const float sc = a.inv_scale ? a.inv_scale[0] : 1.0f;
     const int64_t total = (int64_t)a.Kpad * a.ld;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -74,7 +72,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
                 if (col < a.M) {
                     const int taps = a.KH * a.KW;
                     const int c = k / taps, t = k - c * taps;
-                    v = a.w[((int64_t)col * a.C + c) * taps + t] * sc;
+                    v = a.w[((int64_t)col * a.C + c) * taps + t];
                 }
             } else {
                 if (col < a.C) {
@@ -82,7 +80,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
                     const int m = k / tt, r = k - m * tt;
                     const int th = r / a.TW, tw = r - th * a.TW;
                     const int kh = a.kh0 + a.s * th, kw = a.kw0 + a.s * tw;
-                    v = a.w[(((int64_t)m * a.C + col) * a.KH + kh) * a.KW + kw] * sc;
+                    v = a.w[(((int64_t)m * a.C + col) * a.KH + kh) * a.KW + kw];
                 }
             }
         }
@@ -105,6 +103,7 @@ struct IgParams {
     const float* in;
     float* out;
     const float* bias;   // [M] or null
+    const float* scale;  // device scalar multiplying the contraction (1/sigma of spectral norm) or null
     long long in_bs, out_bs;
     int B, C, H, W;      // gathered tensor: C = reduction channels
     int M, OH, OW;       // produced tensor
@@ -246,6 +245,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
+    const float out_scale = p.scale ? p.scale[0] : 1.0f;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
 #pragma unroll
@@ -266,7 +266,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (p.bias && !split) v += p.bias[m];
+                    if (!split) {
+                        v *= out_scale;
+                        if (p.bias) v += p.bias[m];
+                    }
                     optr[(long long)m * plane] = v;
                 }
             }
@@ -276,15 +279,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
 // out[b, m, :] = bias[m] + sum_z slab[z][b, m, :]
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                                const float* __restrict__ bias, int B, int M, int plane,
+                                                                const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                int B, int M, int plane,
                                                                 long long out_bs, long long slab_stride, int ksplit) {
     const long long per_b = (long long)M * plane;
     const long long total = (long long)B * per_b;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long long b = i / per_b, r = i - b * per_b;
-        float acc = bias ? bias[(int)(r / plane)] : 0.0f;
+        float acc = 0.0f;
         for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
+        if (scale) acc *= scale[0];
+        if (bias) acc += bias[(int)(r / plane)];
         out[b * out_bs + r] = acc;
     }
 }
@@ -333,7 +339,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
-        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.B, p.M, p.OH * p.OW, p.out_bs,
+        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.B, p.M, p.OH * p.OW, p.out_bs,
                                                                          p.slab_stride, p.ksplit);
         LOCATE_LAUNCH_CHECK(who);
     }
@@ -357,9 +363,6 @@ static ConvGeom make_geom(const int* g) {
 }
 
 // geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
-//
-// Workspace layout of locate_conv_fwd / locate_conv_dgrad: [ packed weight panels | split-K slabs ].
-// The same routine runs "dry" (no launches) to size the workspace, so sizing and execution cannot disagree.
 static size_t slab_floats(const IgParams& p, int nmax) {
     int min_kpad = 1 << 30;
     for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
@@ -368,115 +371,138 @@ static size_t slab_floats(const IgParams& p, int nmax) {
     return ks > 1 ? (size_t)ks * p.B * p.M * p.OH * p.OW : 0;
 }
 
-static int run_conv_fwd(const ConvGeom& g, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
-                        const float* bias, float* y, int64_t y_bs, float* ws, hipStream_t st, bool dry, size_t* ws_floats) {
-    PackArgs pa;
-    pa.w = w; pa.inv_scale = inv_scale; pa.out = ws;
-    pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
-    pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
-    pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_BK); pa.ld = round_up(g.M, 32);
-    const size_t pack_floats = (size_t)pa.Kpad * pa.ld;
-    if (!dry)
-        if (int e = launch_pack(pa, st, "locate_conv_fwd(pack)")) return e;
-
-    IgParams p;
-    p.in = x; p.out = y; p.bias = bias; p.in_bs = x_bs; p.out_bs = y_bs;
-    p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW;
-    p.istride = g.stride; p.ostep = 1; p.nphase = 1;
-    IgPhase& ph = p.ph[0];
-    ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
-    ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
-    for (int kh = 0; kh < g.KH; ++kh)
-        for (int kw = 0; kw < g.KW; ++kw) {
-            ph.dy[kh * g.KW + kw] = (signed char)(kh - g.pad_h);
-            ph.dx[kh * g.KW + kw] = (signed char)(kw - g.pad_w);
-        }
-    const int nmax = g.B * g.OH * g.OW;
-    if (ws_floats) *ws_floats = pack_floats + slab_floats(p, nmax);
-    if (dry) return LOCATE_OK;
-    return launch_igemm(p, nmax, ws + pack_floats, st, "locate_conv_fwd(igemm)");
-}
-
-LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) {
-    size_t n = 0;
-    run_conv_fwd(make_geom(geom), nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, true, &n);
-    return n * sizeof(float);
-}
-
-// y[b, m, oh, ow] = bias[m] + inv_scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]
-// x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
-LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* inv_scale,
-                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
-    const ConvGeom g = make_geom(geom);
-    if (int e = geom_check(g, "locate_conv_fwd")) return e;
-    LOCATE_REQUIRE(workspace && x && w && y, "locate_conv_fwd: null pointer");
-    return run_conv_fwd(g, x, x_bs, w, inv_scale, bias, y, y_bs, static_cast<float*>(workspace), as_stream(stream), false,
-                        nullptr);
-}
-
 static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int* T) {
     *k0 = (parity + pad) % s;
     *d0 = (parity + pad - *k0) / s;
     *T = *k0 < K ? (K - *k0 + s - 1) / s : 0;
 }
 
-static int run_conv_dgrad(const ConvGeom& g, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
-                          const float* bias, float* gx, int64_t gx_bs, float* ws, hipStream_t st, bool dry, size_t* ws_floats) {
-    IgParams p;
-    p.in = gy; p.out = gx; p.bias = bias; p.in_bs = gy_bs; p.out_bs = gx_bs;
-    p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
-    p.istride = 1; p.ostep = g.stride; p.nphase = 0;
-    size_t pack_floats = 0;
+// Fills the phase table of R (adjoint = 0) or of its data adjoint (adjoint = 1: one phase per sub-pixel).
+// `panel` is the packed-weight buffer (may be null when only sizes are wanted); with `pack` the packing kernels
+// are launched.  Returns the panel size in floats and the largest per-phase N.
+static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* panel, IgParams& p, int* nmax_out,
+                     size_t* panel_floats, bool pack, hipStream_t st) {
+    size_t off = 0;
     int nmax = 0;
-    for (int py = 0; py < g.stride; ++py)
-        for (int px = 0; px < g.stride; ++px) {
-            int kh0, dy0, TH, kw0, dx0, TW;
-            phase_taps(py, g.pad_h, g.KH, g.stride, &kh0, &dy0, &TH);
-            phase_taps(px, g.pad_w, g.KW, g.stride, &kw0, &dx0, &TW);
-            const int QH = py < g.H ? (g.H - py + g.stride - 1) / g.stride : 0;
-            const int QW = px < g.W ? (g.W - px + g.stride - 1) / g.stride : 0;
-            if (QH == 0 || QW == 0) continue;
-            IgPhase& ph = p.ph[p.nphase++];
-            PackArgs pa;
-            pa.w = w; pa.inv_scale = inv_scale; pa.out = ws + pack_floats;
-            pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
-            pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
-            pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_BK); pa.ld = round_up(g.C, 32);
-            if (!dry)
-                if (int e = launch_pack(pa, st, "locate_conv_dgrad(pack)")) return e;
-            pack_floats += (size_t)pa.Kpad * pa.ld;
-            ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
-            ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
-            for (int th = 0; th < TH; ++th)
-                for (int tw = 0; tw < TW; ++tw) {
-                    ph.dy[th * TW + tw] = (signed char)(dy0 - th);
-                    ph.dx[th * TW + tw] = (signed char)(dx0 - tw);
-                }
-            const int nph = g.B * QH * QW;
-            if (nph > nmax) nmax = nph;
-        }
-    if (ws_floats) *ws_floats = pack_floats + (p.nphase > 0 ? slab_floats(p, nmax) : 0);
-    if (dry) return LOCATE_OK;
-    LOCATE_REQUIRE(p.nphase > 0, "locate_conv_dgrad: empty output");
-    return launch_igemm(p, nmax, ws + pack_floats, st, "locate_conv_dgrad(igemm)");
+    p.nphase = 0;
+    if (!adjoint) {
+        p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW;
+        p.istride = g.stride; p.ostep = 1; p.nphase = 1;
+        PackArgs pa;
+        pa.w = w; pa.out = panel;
+        pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
+        pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
+        pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_BK); pa.ld = round_up(g.M, 32);
+        if (pack)
+            if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
+        IgPhase& ph = p.ph[0];
+        ph.wp = panel; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
+        ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
+        for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw) {
+                ph.dy[kh * g.KW + kw] = (signed char)(kh - g.pad_h);
+                ph.dx[kh * g.KW + kw] = (signed char)(kw - g.pad_w);
+            }
+        off = (size_t)pa.Kpad * pa.ld;
+        nmax = g.B * g.OH * g.OW;
+    } else {
+        p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
+        p.istride = 1; p.ostep = g.stride;
+        for (int py = 0; py < g.stride; ++py)
+            for (int px = 0; px < g.stride; ++px) {
+                int kh0, dy0, TH, kw0, dx0, TW;
+                phase_taps(py, g.pad_h, g.KH, g.stride, &kh0, &dy0, &TH);
+                phase_taps(px, g.pad_w, g.KW, g.stride, &kw0, &dx0, &TW);
+                const int QH = py < g.H ? (g.H - py + g.stride - 1) / g.stride : 0;
+                const int QW = px < g.W ? (g.W - px + g.stride - 1) / g.stride : 0;
+                if (QH == 0 || QW == 0) continue;
+                IgPhase& ph = p.ph[p.nphase++];
+                PackArgs pa;
+                pa.w = w; pa.out = panel ? panel + off : nullptr;
+                pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
+                pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
+                pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_BK); pa.ld = round_up(g.C, 32);
+                if (pack)
+                    if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
+                ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
+                ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
+                for (int th = 0; th < TH; ++th)
+                    for (int tw = 0; tw < TW; ++tw) {
+                        ph.dy[th * TW + tw] = (signed char)(dy0 - th);
+                        ph.dx[th * TW + tw] = (signed char)(dx0 - tw);
+                    }
+                off += (size_t)pa.Kpad * pa.ld;
+                const int nph = g.B * QH * QW;
+                if (nph > nmax) nmax = nph;
+            }
+    }
+    if (nmax_out) *nmax_out = nmax;
+    if (panel_floats) *panel_floats = off;
+    return LOCATE_OK;
 }
 
-LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) {
+// adjoint = 0: panel for locate_conv_fwd; adjoint = 1: panels (one per sub-pixel phase) for locate_conv_dgrad
+LOCATE_API size_t locate_conv_panel_bytes(const int* geom, int adjoint) {
+    IgParams p;
     size_t n = 0;
-    run_conv_dgrad(make_geom(geom), nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, true, &n);
+    conv_plan(make_geom(geom), adjoint, nullptr, nullptr, p, nullptr, &n, false, nullptr);
     return n * sizeof(float);
 }
 
-// gx[b, c, i, j] = bias[c] + inv_scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
-// (data adjoint of R; it is also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]).
+// Re-lays W [M, C, KH, KW] out as the K-major, zero-padded panel(s) the implicit GEMM streams.  Only needs to be
+// redone when W changes (once per optimizer step), not per forward: the spectral-norm 1/sigma is applied in the
+// GEMM epilogue instead of being baked into the weights.
+LOCATE_API int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* panel, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_pack_panel")) return e;
+    LOCATE_REQUIRE(w && panel, "locate_conv_pack_panel: null pointer");
+    IgParams p;
+    return conv_plan(g, adjoint, w, panel, p, nullptr, nullptr, true, as_stream(stream));
+}
+
+static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
+                     const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st, const char* who) {
+    IgParams p;
+    int nmax = 0;
+    if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
+    LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
+    p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
+    LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
+    return launch_igemm(p, nmax, ws, st, who);
+}
+
+static size_t igemm_ws_bytes(const int* geom, int adjoint) {
+    IgParams p;
+    int nmax = 0;
+    conv_plan(make_geom(geom), adjoint, nullptr, nullptr, p, &nmax, nullptr, false, nullptr);
+    return (p.nphase > 0 ? slab_floats(p, nmax) : 0) * sizeof(float);
+}
+
+// split-K slab space (0 when the launch already fills the chip)
+LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) { return igemm_ws_bytes(geom, 0); }
+LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) { return igemm_ws_bytes(geom, 1); }
+
+// y[b, m, oh, ow] = bias[m] + scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]     (panel: adjoint = 0)
+// x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
+LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
+                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_fwd")) return e;
+    LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
+    return run_igemm(g, 0, x, x_bs, panel, scale, bias, y, y_bs, static_cast<float*>(workspace), as_stream(stream),
+                     "locate_conv_fwd");
+}
+
+// gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
+// (data adjoint of R; also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]; panel: adjoint = 1).
 // Every element of gx [B, C, H, W] is written.
-LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* inv_scale,
+LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  const float* bias, float* gx, int64_t gx_bs, void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
-    LOCATE_REQUIRE(workspace && gy && w && gx, "locate_conv_dgrad: null pointer");
-    return run_conv_dgrad(g, gy, gy_bs, w, inv_scale, bias, gx, gx_bs, static_cast<float*>(workspace), as_stream(stream), false,
-                          nullptr);
+    LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
+    return run_igemm(g, 1, gy, gy_bs, panel, scale, bias, gx, gx_bs, static_cast<float*>(workspace), as_stream(stream),
+                     "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         lat, real_, aug_ = self.inputs
+        self._params = [p for net in (step.gen, step.dis) for p in net.parameters()]
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs = []
         self.outputs = {}
@@ -60,4 +61,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
         for g in self.graphs:
             g.replay()
+        # the replayed optimizer kernels changed the weights behind Python's back: bump the version counters so
+        # that any later EAGER use (sampling, evaluation) re-packs its weight panels instead of trusting the cache
+        torch._C._increment_version(self._params)
         return self.outputs

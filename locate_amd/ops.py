@@ -365,6 +365,29 @@ def _bs(t):
     return t.stride(0)
 
 
+# Packed weight panels live ON the weight Parameter object (a plain Python attribute), validated by its version
+# counter: re-packed only after the weight changed (optimizer step, load_state_dict), not on every forward /
+# backward, and freed together with the parameter.
+def _panel_owner(w):
+    base = w._base
+    return w if base is None else base
+
+
+def _panel(owner, w, geom, garr, adjoint):
+    L = lib()
+    cache = owner.__dict__.setdefault("_locate_panels", {})
+    key = (adjoint, tuple(geom[1:10]), w.data_ptr())
+    hit = cache.get(key)
+    ver = owner._version
+    if hit is not None and hit[0] == ver and hit[1].device == w.device:
+        return hit[1]
+    nbytes = L.locate_conv_panel_bytes(garr, adjoint)
+    buf = hit[1] if (hit is not None and hit[1].numel() == max(nbytes, 16) and hit[1].device == w.device) else _ws(nbytes, w.device)
+    check(L.locate_conv_pack_panel(garr, adjoint, _p(w), _p(buf), _stream()), "locate_conv_pack_panel")
+    cache[key] = (ver, buf)
+    return buf
+
+
 def sn_power_iteration(w_bar, u, v):
     """One power iteration on (u, v) IN PLACE (untracked, like the reference's `.data` writes,
     libs/spectral_norm.py:26-29).  Returns (sigma[2] = {sigma, 1/sigma}, wv[h] = W v)."""
@@ -395,6 +418,7 @@ class SNConvFn(torch.autograd.Function):
         if not _dense_planes(x):
             x = x.contiguous()
         w = _c(w_bar, "weight_bar")
+        owner = _panel_owner(w_bar)
         geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
         garr = _geom(geom)
         y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
@@ -402,13 +426,15 @@ class SNConvFn(torch.autograd.Function):
         b = _c(bias) if bias is not None else None
         if spec.kind == "conv":
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(w), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws), st), "locate_conv_fwd")
+            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws),
+                                    st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(w), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws), st),
-                  "locate_conv_dgrad")
+            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), _p(b), _p(y), _bs(y),
+                                      _p(ws), st), "locate_conv_dgrad")
         ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
+        ctx.owner = owner
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
         return y
 
@@ -428,12 +454,12 @@ class SNConvFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             if spec.kind == "conv":
                 ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(w), _p(inv_sigma), None, _p(gx), _bs(gx), _p(ws), st),
-                      "locate_conv_dgrad")
+                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 1)), _p(inv_sigma), None, _p(gx),
+                                          _bs(gx), _p(ws), st), "locate_conv_dgrad")
             else:
                 ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(w), _p(inv_sigma), None, _p(gx), _bs(gx), _p(ws), st),
-                      "locate_conv_fwd")
+                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 0)), _p(inv_sigma), None, _p(gx),
+                                        _bs(gx), _p(ws), st), "locate_conv_fwd")
         if need_w or need_u or need_v:
             g_wn = torch.empty_like(w)     # gradient w.r.t. the normalised weight W_bar / sigma
             ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)

@@ -76,4 +76,6 @@ class Nadam(torch.optim.Optimizer):
             check(lib().locate_nadam_step(t_dev.data_ptr(), coef.data_ptr(), c_dev.data_ptr(), n_t, n_c, float(group["lr"]),
                                           float(b1), float(b2), float(group["eps"]), float(group["schedule_decay"]),
                                           torch.cuda.current_stream().cuda_stream), "locate_nadam_step")
+            # the kernel writes through raw pointers: tell autograd / the packed-panel cache that the weights changed
+            torch._C._increment_version(plist)
         return loss

@@ -145,8 +145,8 @@ def test_graph_replay_equals_eager():
     cfg, G1, D1, step1, dev = _build_tiny(z, True)
     _, G2, D2, step2, _ = _build_tiny(z, True)
     lat, real, aug = (T(z["step1/" + k]).to(dev) for k in ("latent", "real", "aug"))
-    runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations + the captured one
-    for _ in range(3):
+    runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations, then capture (no execution)
+    for _ in range(2):
         out1 = step1(lat, real, aug)
     for _ in range(2):                                               # two replays
         out1 = step1(lat, real, aug)
