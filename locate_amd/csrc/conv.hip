@@ -96,7 +96,11 @@ struct IgPhase {
     const float* wp;   // packed weights [Kpad][ld]
     int K, Kpad, ld, T;
     int oy0, ox0, QH, QW;
-    signed char dy[IG_MAXT], dx[IG_MAXT];
+    int kstep_c, kstep_t;        // IG_BK / T and IG_BK % T: how (channel, tap) advance per K step
+    // taps form a TH x TW grid, tap t = th*TW + tw reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw):
+    // pure arithmetic on the scalar unit, no table lookups in the gather loop
+    int TW, tw_magic;            // th = (t * tw_magic) >> 16  (exact for t < 32)
+    int dy0, dys, dx0, dxs;
 };
 
 struct IgParams {
@@ -126,7 +130,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     __shared__ __attribute__((aligned(16))) float As[2][IG_BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][IG_BK][BN];
-    __shared__ int doff_s[IG_MAXT];
 
     const int zphase = blockIdx.z / p.ksplit, zsplit = blockIdx.z - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
@@ -139,8 +142,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     const int wm = wid / WGN, wn = wid % WGN;
     const int HW = p.H * p.W;
     const int T = ph.T;
-
-    if (tid < IG_MAXT) doff_s[tid] = tid < T ? (int)ph.dy[tid] * p.W + (int)ph.dx[tid] : 0;
+    const int TWs = ph.TW, tw_magic = ph.tw_magic, dy0 = ph.dy0, dys = ph.dys, dx0 = ph.dx0, dxs = ph.dxs;
 
     // ---- per-thread gather column (fixed for the whole K loop)
     const int ncol = tid % BN;
@@ -158,13 +160,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         in_col += (long long)b * p.in_bs + (long long)iy0 * p.W + ix0;
         if (n_ok) {
             for (int t = 0; t < T; ++t) {
-                const bool ok = (unsigned)(iy0 + ph.dy[t]) < (unsigned)p.H && (unsigned)(ix0 + ph.dx[t]) < (unsigned)p.W;
+                const int th = (t * ph.tw_magic) >> 16, tw = t - th * ph.TW;
+                const bool ok = (unsigned)(iy0 + ph.dy0 + ph.dys * th) < (unsigned)p.H &&
+                                (unsigned)(ix0 + ph.dx0 + ph.dxs * tw) < (unsigned)p.W;
                 tapmask |= (ok ? 1u : 0u) << t;
             }
         }
     }
-    __syncthreads();   // doff_s ready
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -175,31 +177,43 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     float breg[KPT];
     float4 areg[A_PT];
+    int gc = 0, gt = 0;    // (channel, tap) of this wave's first gathered row in the NEXT load_tiles call
+    unsigned bmask = 0;    // validity bits of breg[]; applied when the tile is written to LDS
 
     auto load_tiles = [&](int k0) {
         // weights: K-major panel, rows always exist (Kpad), columns guarded by ld
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             const int idx = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < A_F4) {
-                const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
-                const int col = m0 + c4 * 4;
-                if (col < ph.ld) v = *reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + col);
-            }
-            areg[i] = v;
+            // unconditional load from a clamped address; out-of-panel columns are zeroed when the tile is stored, so
+            // that no instruction consumes the loaded value (and no s_waitcnt lands) before the MFMA block
+            const int idc = idx < A_F4 ? idx : 0;
+            const int row = idc / (BM / 4), c4 = idc - row * (BM / 4);
+            const int col = m0 + c4 * 4;
+            areg[i] = *reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + (col < ph.ld ? col : 0));
         }
-        // activations: (c, t) is wave-uniform
+        // activations: (c, t) is wave-uniform -> tap lookups and offset arithmetic run on the scalar unit; the load is
+        // unconditional (masked elements read element 0 of the column and are zeroed by a select) so that all KPT
+        // loads of a thread are in flight together instead of being serialised by exec-mask branches
         int kk = k0 + kgrp * KPT;
-        int c = kk / T, t = kk - c * T;
+        int c = gc, t = gt;
+        bmask = 0;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            float v = 0.0f;
-            if (kk < ph.K && ((tapmask >> t) & 1u)) v = in_col[(long long)c * HW + doff_s[t]];
-            breg[j] = v;
+            const int ts = __builtin_amdgcn_readfirstlane(t);
+            const int cs = __builtin_amdgcn_readfirstlane(c);
+            const int th = (ts * tw_magic) >> 16, tw = ts - th * TWs;
+            const int off = cs * HW + (dy0 + dys * th) * p.W + dx0 + dxs * tw;
+            const bool valid = kk < ph.K && ((tapmask >> ts) & 1u);
+            breg[j] = in_col[valid ? off : 0];
+            bmask |= (valid ? 1u : 0u) << j;
             ++kk; ++t;
             if (t == T) { t = 0; ++c; }
         }
+        // advance the group's first (channel, tap) to the next K step without a division
+        gt += ph.kstep_t;
+        gc += ph.kstep_c;
+        if (gt >= T) { gt -= T; ++gc; }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
@@ -207,11 +221,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
             const int idx = tid + i * 256;
             if (idx < A_F4) {
                 const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
-                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg[i];
+                const bool ok = m0 + c4 * 4 < ph.ld;
+                float4 v = areg[i];
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = v;
             }
         }
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = breg[j];
+        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask >> j) & 1u) ? breg[j] : 0.0f;
     };
 
     const int total_steps = ph.Kpad / IG_BK;
@@ -220,6 +237,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     int nsteps = total_steps - step0;
     if (nsteps > per_split) nsteps = per_split;
     if (nsteps < 0) nsteps = 0;
+    {
+        const int kfirst = step0 * IG_BK + kgrp * KPT;
+        gc = kfirst / T;
+        gt = kfirst - gc * T;
+    }
     if (nsteps > 0) {
         load_tiles(step0 * IG_BK);
         store_tiles(0);
@@ -398,11 +420,9 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         IgPhase& ph = p.ph[0];
         ph.wp = panel; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
         ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
-        for (int kh = 0; kh < g.KH; ++kh)
-            for (int kw = 0; kw < g.KW; ++kw) {
-                ph.dy[kh * g.KW + kw] = (signed char)(kh - g.pad_h);
-                ph.dx[kh * g.KW + kw] = (signed char)(kw - g.pad_w);
-            }
+        ph.kstep_c = IG_BK / ph.T; ph.kstep_t = IG_BK % ph.T;
+        ph.TW = g.KW; ph.tw_magic = (65536 + g.KW - 1) / g.KW;
+        ph.dy0 = -g.pad_h; ph.dys = 1; ph.dx0 = -g.pad_w; ph.dxs = 1;
         off = (size_t)pa.Kpad * pa.ld;
         nmax = g.B * g.OH * g.OW;
     } else {
@@ -426,11 +446,9 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                     if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
                 ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
                 ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
-                for (int th = 0; th < TH; ++th)
-                    for (int tw = 0; tw < TW; ++tw) {
-                        ph.dy[th * TW + tw] = (signed char)(dy0 - th);
-                        ph.dx[th * TW + tw] = (signed char)(dx0 - tw);
-                    }
+                ph.kstep_c = IG_BK / ph.T; ph.kstep_t = IG_BK % ph.T;
+                ph.TW = TW > 0 ? TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
+                ph.dy0 = dy0; ph.dys = -1; ph.dx0 = dx0; ph.dxs = -1;
                 off += (size_t)pa.Kpad * pa.ld;
                 const int nph = g.B * QH * QW;
                 if (nph > nmax) nmax = nph;
@@ -570,6 +588,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     const int Q = p.OH * p.OW;
 
     float greg[G_PT], xreg[X_PT];
+    unsigned gmask = 0, xmask = 0;   // validity bits, applied when the tiles are written to LDS (loads are unconditional
+                                     // from clamped addresses so that they all issue back to back, see conv_igemm_kernel)
     auto load_tiles = [&](int nb) {
         const int n = nb + nl;
         const bool ok = n < n_end;
@@ -577,27 +597,32 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         const int b = nn / Q, q = nn - b * Q;
         const int oh = q / p.OW, ow = q - oh * p.OW;
         const float* gp = p.gy + (long long)b * p.gy_bs + q;
+        gmask = 0;
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
             const int m = m0 + sub + 8 * i;
-            greg[i] = (ok && m < p.M) ? gp[(long long)m * Q] : 0.0f;
+            const bool v = ok && m < p.M;
+            greg[i] = gp[v ? (long long)m * Q : 0];
+            gmask |= (v ? 1u : 0u) << i;
         }
         const int iy0 = oh * p.stride, ix0 = ow * p.stride;
         const float* xp = p.x + (long long)b * p.x_bs + (long long)iy0 * p.W + ix0;
+        xmask = 0;
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
             const int rl = sub + 8 * i;
             const int off = rt_off[rl];
             const bool v = ok && off != (-2147483647 - 1) && (unsigned)(iy0 + rt_dy[rl]) < (unsigned)p.H &&
                            (unsigned)(ix0 + rt_dx[rl]) < (unsigned)p.W;
-            xreg[i] = v ? xp[off] : 0.0f;
+            xreg[i] = xp[v ? off : -(iy0 * p.W + ix0)];   // masked lanes read element 0 of the batch image (always valid)
+            xmask |= (v ? 1u : 0u) << i;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < G_PT; ++i) Gs[buf][nl][sub + 8 * i] = greg[i];
+        for (int i = 0; i < G_PT; ++i) Gs[buf][nl][sub + 8 * i] = ((gmask >> i) & 1u) ? greg[i] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < X_PT; ++i) Xs[buf][nl][sub + 8 * i] = xreg[i];
+        for (int i = 0; i < X_PT; ++i) Xs[buf][nl][sub + 8 * i] = ((xmask >> i) & 1u) ? xreg[i] : 0.0f;
     };
 
     const int nsteps = (n_end - n_begin + WG_BK - 1) / WG_BK;

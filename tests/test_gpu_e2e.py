@@ -16,11 +16,17 @@ def sub(z, prefix):
 
 
 def assert_step_close(got, want, lr, step, what):
-    """Post-Nadam parameters in units of the learning rate (see tests/test_oracle_golden.py)."""
-    d = (T(got).double() - T(want).double()).abs()
+    """Post-Nadam parameters, in units of the learning rate.  The first Nadam steps move every weight by
+    ~lr * g / (|g| + eps), i.e. by about +-lr whatever the size of g: an element whose gradient is of the size of
+    its own fp32 rounding noise can flip sign and land a full step away (the reference's fp32-vs-fp64 self-noise
+    does the same).  So the bound is statistical: mean deviation <= 1e-4 lr, at most 0.1 % of the elements off by
+    more than 1 % of a step, and nothing further away than a sign flip allows (x10 on the compounded 2nd step)."""
+    d = (torch.as_tensor(got).double() - torch.as_tensor(want).double()).abs()
     k = 1 if step == 1 else 10
-    assert float(d.max()) <= 0.05 * lr * k, "%s: max |delta| = %.3e lr" % (what, float(d.max()) / lr)
     assert float(d.mean()) <= 1e-4 * lr * k, "%s: mean |delta| = %.3e lr" % (what, float(d.mean()) / lr)
+    assert float((d > 0.01 * lr * k).double().mean()) <= 1e-3, "%s: %.3e of the elements off by > 1%% lr" % (
+        what, float((d > 0.01 * lr * k).double().mean()))
+    assert float(d.max()) <= 2.5 * lr, "%s: max |delta| = %.3e lr" % (what, float(d.max()) / lr)
 
 
 def _build_tiny(z, batched_sn=False):

@@ -1,0 +1,105 @@
+"""Micro-benchmark of the implicit-GEMM kernels on the shapes of config 2 (64x64, batch 64): forward, data
+gradient and weight gradient of every distinct conv stage, timed with HIP events on the launch stream.
+Usage (GPU box): python tools/bench_conv.py [--reps 20]"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from locate_amd import ops  # noqa: E402
+from locate_amd._lib import check, lib  # noqa: E402
+
+# name, kind, Cin, Cout, k, s, p, H (input side), B
+SHAPES = [
+    ("G.b1 convT4x4 768", "convT", 768, 768, 4, 2, 1, 4, 64),
+    ("G.b2 convT4x4 384", "convT", 384, 384, 4, 2, 1, 8, 64),
+    ("G.b3 convT4x4 192", "convT", 192, 192, 4, 2, 1, 16, 64),
+    ("G.b4 convT4x4 96", "convT", 96, 96, 4, 2, 1, 32, 64),
+    ("G.b4 convT1x1 96->48", "convT", 96, 48, 1, 1, 0, 64, 64),
+    ("G.b3 convT1x1 192->96", "convT", 192, 96, 1, 1, 0, 32, 64),
+    ("G.out conv3x3 48", "conv", 48, 48, 3, 1, 1, 64, 64),
+    ("G.sa conv1x1 48 (N=4096)", "conv", 48, 48, 1, 1, 0, 64, 64),
+    ("D.stem conv5x5 3", "conv", 3, 3, 5, 2, 2, 64, 64),
+    ("D.b0 conv5x5 32", "conv", 32, 32, 5, 2, 2, 32, 64),
+    ("D.b1 conv5x5 64", "conv", 64, 64, 5, 2, 2, 16, 64),
+    ("D.b2 conv5x5 128", "conv", 128, 128, 5, 2, 2, 8, 64),
+    ("D.b3 conv5x5 256", "conv", 256, 256, 5, 2, 2, 4, 64),
+    ("D.b4 conv5x5 512", "conv", 512, 512, 5, 2, 2, 2, 64),
+    ("D.b3 conv1x1 256->512", "conv", 256, 512, 1, 1, 0, 2, 64),
+]
+
+
+def time_it(fn, reps):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
+    tot = [0.0, 0.0, 0.0]
+    for name, kind, cin, cout, k, s, p, H, B in SHAPES:
+        spec = ops.ConvSpec(kind, k, k, s, p, p)
+        wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+        w = torch.randn(wshape, device=dev) * 0.05
+        x = torch.randn(B, cin, H, H, device=dev)
+        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+        garr = (ctypes.c_int * 12)(*geom)
+        y = torch.empty(out_shape, device=dev)
+        gy = torch.randn(out_shape, device=dev)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w)
+        one = torch.ones(1, device=dev)
+        pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0), 16), dtype=torch.uint8, device=dev)
+        pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1), 16), dtype=torch.uint8, device=dev)
+        check(L.locate_conv_pack_panel(garr, 0, w.data_ptr(), pan0.data_ptr(), st))
+        check(L.locate_conv_pack_panel(garr, 1, w.data_ptr(), pan1.data_ptr(), st))
+        ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+        ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+        ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+
+        def r_fwd(inp, out):      # R forward
+            check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), None, out.data_ptr(),
+                                    out.stride(0), ws_f.data_ptr(), st))
+
+        def r_dgrad(inp, out):    # R data adjoint
+            check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), None, out.data_ptr(),
+                                      out.stride(0), ws_d.data_ptr(), st))
+
+        if kind == "conv":
+            fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
+            wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
+                                                    ws_w.data_ptr(), st))
+        else:
+            fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
+            wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
+                                                    ws_w.data_ptr(), st))
+        OH = out_shape[2]
+        if kind == "conv":
+            flops = 2.0 * B * OH * OH * cout * cin * k * k
+        else:
+            flops = 2.0 * B * H * H * cout * cin * k * k        # every input pixel meets every tap once
+        ms = [time_it(f, args.reps) for f in (fwd, dgr, wgr)]
+        for i in range(3):
+            tot[i] += ms[i]
+        print("%-28s %s" % (name, "  ".join("%6.3f|%6.1f" % (m, flops / m / 1e9) for m in ms)), flush=True)
+    print("%-28s %s" % ("sum (ms)", "  ".join("%13.3f" % t for t in tot)))
+
+
+if __name__ == "__main__":
+    main()
