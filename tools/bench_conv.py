@@ -47,6 +47,7 @@ def time_it(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the stage name")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = lib()
@@ -54,6 +55,8 @@ def main():
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
     for name, kind, cin, cout, k, s, p, H, B in SHAPES:
+        if args.only and args.only not in name:
+            continue
         spec = ops.ConvSpec(kind, k, k, s, p, p)
         wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
         w = torch.randn(wshape, device=dev) * 0.05
