@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define IG_BK 16
 #define IG_MAXT 32
+#define IG_ALU_PER_MFMA 8
 
 struct ConvGeom {
     int B, C, H, W;            // input of R
@@ -177,49 +178,68 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     float breg[KPT];
     float4 areg[A_PT];
-    int gc = 0, gt = 0;    // (channel, tap) of this wave's first gathered row in the NEXT load_tiles call
     unsigned bmask = 0;    // validity bits of breg[]; applied when the tile is written to LDS
+    int gc = 0, gt = 0;    // (channel, tap) of this wave's first gathered row at the next address computation
 
-    auto load_tiles = [&](int k0) {
-        // weights: K-major panel, rows always exist (Kpad), columns guarded by ld
+    // Addresses of one K step's global loads.  They are computed ONE STEP AHEAD of the loads that use them, so the
+    // scalar/vector address arithmetic sits inside the MFMA block (where it is free) and the loads themselves are
+    // the first instructions of an iteration (a full MFMA block of latency cover).
+    const float* baddr[KPT];
+    const float4* aaddr[A_PT];
+    unsigned amask_next = 0;
+
+    int ck = 0, cc = 0, ct = 0;     // running (k, channel, tap) of the address computation in progress
+    unsigned cm = 0;
+    auto calc_begin = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
+            // out-of-panel columns load column 0 and are zeroed when the tile is stored
             const int idx = tid + i * 256;
-            // unconditional load from a clamped address; out-of-panel columns are zeroed when the tile is stored, so
-            // that no instruction consumes the loaded value (and no s_waitcnt lands) before the MFMA block
-            const int idc = idx < A_F4 ? idx : 0;
+            const int idc = ((i + 1) * 256 <= A_F4 || idx < A_F4) ? idx : 0;
             const int row = idc / (BM / 4), c4 = idc - row * (BM / 4);
             const int col = m0 + c4 * 4;
-            areg[i] = *reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + (col < ph.ld ? col : 0));
+            aaddr[i] = reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + (col < ph.ld ? col : 0));
         }
-        // activations: (c, t) is wave-uniform -> tap lookups and offset arithmetic run on the scalar unit; the load is
-        // unconditional (masked elements read element 0 of the column and are zeroed by a select) so that all KPT
-        // loads of a thread are in flight together instead of being serialised by exec-mask branches
-        int kk = k0 + kgrp * KPT;
-        int c = gc, t = gt;
-        bmask = 0;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int ts = __builtin_amdgcn_readfirstlane(t);
-            const int cs = __builtin_amdgcn_readfirstlane(c);
-            const int th = (ts * tw_magic) >> 16, tw = ts - th * TWs;
-            const int off = cs * HW + (dy0 + dys * th) * p.W + dx0 + dxs * tw;
-            const bool valid = kk < ph.K && ((tapmask >> ts) & 1u);
-            breg[j] = in_col[valid ? off : 0];
-            bmask |= (valid ? 1u : 0u) << j;
-            ++kk; ++t;
-            if (t == T) { t = 0; ++c; }
-        }
+        ck = k0 + kgrp * KPT;
+        cc = gc; ct = gt; cm = 0;
         // advance the group's first (channel, tap) to the next K step without a division
         gt += ph.kstep_t;
         gc += ph.kstep_c;
         if (gt >= T) { gt -= T; ++gc; }
     };
+    // activations: (c, t) is wave-uniform -> offset arithmetic runs on the scalar unit; masked elements read
+    // element 0 of the column (always mapped) and are zeroed by a select at store time, so the loads carry no
+    // exec-mask branches and all KPT of them are in flight together
+    auto calc_elem = [&](int j) {
+        const int ts = __builtin_amdgcn_readfirstlane(ct);
+        const int cs = __builtin_amdgcn_readfirstlane(cc);
+        const int th = (ts * tw_magic) >> 16, tw = ts - th * TWs;
+        const int off = cs * HW + (dy0 + dys * th) * p.W + dx0 + dxs * tw;
+        const bool valid = ck < ph.K && ((tapmask >> ts) & 1u);
+        baddr[j] = in_col + (valid ? off : 0);
+        cm |= (valid ? 1u : 0u) << j;
+        ++ck; ++ct;
+        if (ct == T) { ct = 0; ++cc; }
+    };
+    auto calc_end = [&]() { amask_next = cm; };
+    auto calc_addr = [&](int k0) {
+        calc_begin(k0);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) calc_elem(j);
+        calc_end();
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) areg[i] = *aaddr[i];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) breg[j] = *baddr[j];
+        bmask = amask_next;
+    };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             const int idx = tid + i * 256;
-            if (idx < A_F4) {
+            if ((i + 1) * 256 <= A_F4 || idx < A_F4) {
                 const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
                 const bool ok = m0 + c4 * 4 < ph.ld;
                 float4 v = areg[i];
@@ -242,15 +262,24 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         gc = kfirst / T;
         gt = kfirst - gc * T;
     }
+    const int klast = ph.Kpad - IG_BK;
+    auto clampk = [&](int k) { return k > klast ? klast : k; };   // past-the-end prefetches re-read the last rows
     if (nsteps > 0) {
-        load_tiles(step0 * IG_BK);
+        calc_addr(clampk(step0 * IG_BK));
+        issue_loads();
+        calc_addr(clampk((step0 + 1) * IG_BK));
         store_tiles(0);
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_tiles((step0 + s + 1) * IG_BK);
+        // One basic block per iteration: loads of step s+1 first (pinned), then the MFMAs of step s with the address
+        // arithmetic of step s+2 free to interleave, then the LDS writes of step s+1.  On the last iterations the
+        // prefetches are redundant (clamped to the final panel rows, written to the idle buffer) but branch-free.
+        issue_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        calc_begin(clampk((step0 + s + 2) * IG_BK));
 #pragma unroll
         for (int k2 = 0; k2 < IG_BK / 2; ++k2) {
             float a[TM], b[TN];
@@ -262,8 +291,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            // a slice of the NEXT-next step's address arithmetic rides in the shadow of this k-pair's MFMAs (an fp32
+            // 32x32x2 MFMA holds the matrix pipe for 64 cycles); the fence keeps the slices where they are put
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (j * (IG_BK / 2) / KPT == k2) calc_elem(j);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < nsteps) store_tiles(buf ^ 1);
+        calc_end();
+        store_tiles(buf ^ 1);
         __syncthreads();
     }
 

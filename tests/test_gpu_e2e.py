@@ -21,6 +21,10 @@ def assert_step_close(got, want, lr, step, what):
     its own fp32 rounding noise can flip sign and land a full step away (the reference's fp32-vs-fp64 self-noise
     does the same).  So the bound is statistical: mean deviation <= 1e-4 lr, at most 0.1 % of the elements off by
     more than 1 % of a step, and nothing further away than a sign flip allows (x10 on the compounded 2nd step)."""
+    if what.endswith("weight_u") or what.endswith("weight_v"):
+        # power-iteration state, not an optimizer-driven quantity (G's u/v are never trainable; D's are overwritten
+        # by the next forward): plain normalised tolerance
+        return assert_close(got, want, 2e-5 if step == 1 else 3e-4, what)
     d = (torch.as_tensor(got).double() - torch.as_tensor(want).double()).abs()
     k = 1 if step == 1 else 10
     assert float(d.mean()) <= 1e-4 * lr * k, "%s: mean |delta| = %.3e lr" % (what, float(d.mean()) / lr)
