@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     int ck = 0, cc = 0, ct = 0;     // running (k, channel, tap) of the address computation in progress
     unsigned cm = 0;
-    auto calc_begin = [&](int k0) {
+    auto calc_begin = [&](int k0) {      // k0 may run past the end of K: the prefetches of the last iterations
+        const int ka = k0 > ph.Kpad - IG_BK ? ph.Kpad - IG_BK : k0;   // A: re-read the final panel rows (in bounds)
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             // out-of-panel columns load column 0 and are zeroed when the tile is stored
@@ -198,9 +199,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
             const int idc = ((i + 1) * 256 <= A_F4 || idx < A_F4) ? idx : 0;
             const int row = idc / (BM / 4), c4 = idc - row * (BM / 4);
             const int col = m0 + c4 * 4;
-            aaddr[i] = reinterpret_cast<const float4*>(ph.wp + (long long)(k0 + row) * ph.ld + (col < ph.ld ? col : 0));
+            aaddr[i] = reinterpret_cast<const float4*>(ph.wp + (long long)(ka + row) * ph.ld + (col < ph.ld ? col : 0));
         }
-        ck = k0 + kgrp * KPT;
+        ck = k0 + kgrp * KPT;       // B: k >= K masks the element (its channel index would be out of range)
         cc = gc; ct = gt; cm = 0;
         // advance the group's first (channel, tap) to the next K step without a division
         gt += ph.kstep_t;
@@ -262,12 +263,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         gc = kfirst / T;
         gt = kfirst - gc * T;
     }
-    const int klast = ph.Kpad - IG_BK;
-    auto clampk = [&](int k) { return k > klast ? klast : k; };   // past-the-end prefetches re-read the last rows
     if (nsteps > 0) {
-        calc_addr(clampk(step0 * IG_BK));
+        calc_addr(step0 * IG_BK);
         issue_loads();
-        calc_addr(clampk((step0 + 1) * IG_BK));
+        calc_addr((step0 + 1) * IG_BK);
         store_tiles(0);
     }
     __syncthreads();
@@ -279,7 +278,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         // prefetches are redundant (clamped to the final panel rows, written to the idle buffer) but branch-free.
         issue_loads();
         __builtin_amdgcn_sched_barrier(0);
-        calc_begin(clampk((step0 + s + 2) * IG_BK));
+        calc_begin((step0 + s + 2) * IG_BK);
 #pragma unroll
         for (int k2 = 0; k2 < IG_BK / 2; ++k2) {
             float a[TM], b[TN];
