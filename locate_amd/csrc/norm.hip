@@ -171,53 +171,46 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
     }
 }
 
-// One block.  Threads sweep the B*C planes (coalesced); per-channel sums over the batch go through LDS float
-// atomics when C fits (C <= 4096: every shipped width), otherwise through a per-channel loop.
+// One block, deterministic (fixed summation order - no atomics - so that eager and hipGraph replays agree bit for
+// bit): thread (c, grp) sums its share of the batch for channel c, the groups meet through LDS in a fixed order.
 __global__ void __launch_bounds__(1024) norm_bwd_final_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
                                                               const float* __restrict__ stats, const float* __restrict__ scale,
                                                               int scale_per_sample, float* __restrict__ dscale,
                                                               float* __restrict__ dbias, float* __restrict__ consts, int B,
                                                               int C, int hw) {
     __shared__ double scratch[16];
-    __shared__ float acc_b[4096], acc_y[4096];
+    __shared__ float part_b[1024], part_y[1024];
     const double s = (double)stats[1];
     const float sf = stats[1];
     const int64_t planes = (int64_t)B * C;
     const double n = (double)planes * (double)hw;
     double sum_yg = 0.0, sum_yxg = 0.0;
-    if (C <= 4096) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) { acc_b[c] = 0.0f; acc_y[c] = 0.0f; }
-        __syncthreads();
-        for (int64_t p = threadIdx.x; p < planes; p += blockDim.x) {
-            const int c = (int)(p % C);
-            const float s1 = S1[p], s2 = S2[p];
-            const float y = scale[scale_per_sample ? p : c];
-            atomicAdd(&acc_b[c], s1);
-            if (scale_per_sample) dscale[p] = s2 / sf;
-            else atomicAdd(&acc_y[c], s2);
-            sum_yg += (double)y * (double)s1;
-            sum_yxg += (double)y * (double)s2;
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            dbias[c] = acc_b[c];
-            if (!scale_per_sample) dscale[c] = acc_y[c] / sf;
-        }
-    } else {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            double db = 0.0, dy = 0.0;
-            for (int b = 0; b < B; ++b) {
+    for (int c0 = 0; c0 < C; c0 += 1024) {                 // channel tiles of up to 1024 (one pass for every shipped width)
+        const int cw = min(1024, C - c0);
+        const int groups = max(1, 1024 / cw);
+        const int cl = threadIdx.x % cw, grp = threadIdx.x / cw;
+        float db = 0.0f, dy = 0.0f;
+        if (grp < groups) {
+            const int c = c0 + cl;
+            for (int b = grp; b < B; b += groups) {
                 const int64_t p = (int64_t)b * C + c;
-                const double s1 = S1[p], s2 = S2[p];
-                const double y = scale[scale_per_sample ? p : c];
+                const float s1 = S1[p], s2 = S2[p];
+                const float y = scale[scale_per_sample ? p : c];
                 db += s1;
-                if (scale_per_sample) dscale[p] = (float)(s2 / s);
+                if (scale_per_sample) dscale[p] = s2 / sf;
                 else dy += s2;
-                sum_yg += y * s1;
-                sum_yxg += y * s2;
+                sum_yg += (double)y * (double)s1;
+                sum_yxg += (double)y * (double)s2;
             }
-            dbias[c] = (float)db;
-            if (!scale_per_sample) dscale[c] = (float)(dy / s);
+        }
+        __syncthreads();
+        if (grp < groups) { part_b[grp * cw + cl] = db; part_y[grp * cw + cl] = dy; }
+        __syncthreads();
+        if ((int)threadIdx.x < cw) {
+            float tb = 0.0f, ty = 0.0f;
+            for (int g2 = 0; g2 < groups; ++g2) { tb += part_b[g2 * cw + threadIdx.x]; ty += part_y[g2 * cw + threadIdx.x]; }
+            dbias[c0 + threadIdx.x] = tb;
+            if (!scale_per_sample) dscale[c0 + threadIdx.x] = ty / sf;
         }
     }
     sum_yg = block_sum<double>(sum_yg, scratch);
@@ -290,43 +283,36 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
 // per-channel sum over batch and space: out[c] = sum_{b,hw} g[b, c, hw]   (bias gradients of the 1x1 skip
 // convs, scale.py:28-34, and of the style Linears, linear.py:10)
 // ---------------------------------------------------------------------------------------------
-// grid = (C, nsplit): block (c, z) sums its share of the batch for channel c with 16-byte loads; partial sums meet
-// through one float atomic per block on a zeroed output (<= 8 adders per address).
-__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int C,
-                                                          int hw, int64_t batch_stride) {
+// One 1024-thread block per channel, 16-byte loads, fixed summation order (deterministic).
+__global__ void __launch_bounds__(1024) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int C,
+                                                           int hw, int64_t batch_stride) {
     __shared__ float scratch[16];
     const int c = blockIdx.x;
     float acc = 0.0f;
-    for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        const float* gp = g + (int64_t)b * batch_stride + (int64_t)c * hw;
-        if ((hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(gp) & 15) == 0)) {
-            const float4* g4 = reinterpret_cast<const float4*>(gp);
-            for (int i = threadIdx.x; i < (hw >> 2); i += blockDim.x) {
-                const float4 v = g4[i];
-                acc += (v.x + v.y) + (v.z + v.w);
-            }
-        } else {
-            for (int i = threadIdx.x; i < hw; i += blockDim.x) acc += gp[i];
+    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (vec) {
+        const int hw4 = hw >> 2;
+        const int total = B * hw4;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int b = i / hw4, r = i - b * hw4;
+            const float4 v = reinterpret_cast<const float4*>(g + (int64_t)b * batch_stride + (int64_t)c * hw)[r];
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        const int total = B * hw;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int b = i / hw, r = i - b * hw;
+            acc += g[(int64_t)b * batch_stride + (int64_t)c * hw + r];
         }
     }
     acc = block_sum<float>(acc, scratch);
-    if (threadIdx.x == 0) atomicAdd(&out[c], acc);
+    if (threadIdx.x == 0) out[c] = acc;
 }
 
 LOCATE_API int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream) {
-    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && batch_stride >= (int64_t)C * hw, "locate_channel_sum: bad shape");
-    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), as_stream(stream)) != hipSuccess) {
-        locate_set_error("locate_channel_sum: memset failed");
-        return LOCATE_ERR_LAUNCH;
-    }
-    int nsplit = 1;
-    if ((int64_t)C < 512 && (int64_t)B * hw >= 4096) {
-        nsplit = (int)(512 / C);
-        if (nsplit > 8) nsplit = 8;
-        if (nsplit > B) nsplit = B;
-        if (nsplit < 1) nsplit = 1;
-    }
-    channel_sum_kernel<<<dim3(C, nsplit), 256, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride);
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && batch_stride >= (int64_t)C * hw && (int64_t)B * hw < (1ll << 31),
+                   "locate_channel_sum: bad shape");
+    channel_sum_kernel<<<C, 1024, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride);
     LOCATE_LAUNCH_CHECK("locate_channel_sum");
     return LOCATE_OK;
 }
