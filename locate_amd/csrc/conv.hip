@@ -21,10 +21,11 @@
 // Tiling: 256 threads = 4 waves, block tile BM x 128 (BM in {128, 96, 64, 32}), K step 16, double-buffered
 // LDS with register prefetch of the next K step, one barrier per step.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define IG_BK 16
+#define IG_KPAD 32          // panels are zero-padded to a multiple of this many K rows (covers BK = 16 and 32)
 #define IG_MAXT 32
 #define IG_ALU_PER_MFMA 8
 
@@ -97,7 +98,6 @@ struct IgPhase {
     const float* wp;   // packed weights [Kpad][ld]
     int K, Kpad, ld, T;
     int oy0, ox0, QH, QW;
-    int kstep_c, kstep_t;        // IG_BK / T and IG_BK % T: how (channel, tap) advance per K step
     // taps form a TH x TW grid, tap t = th*TW + tw reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw):
     // pure arithmetic on the scalar unit, no table lookups in the gather loop
     int TW, tw_magic;            // th = (t * tw_magic) >> 16  (exact for t < 32)
@@ -119,18 +119,19 @@ struct IgParams {
     IgPhase ph[4];
 };
 
-template <int WGM, int WGN, int TM, int TN>
+// BK: K elements per step (16 or 32).  PF: prefetch the next k-pair's LDS fragments before the current MFMAs.
+template <int WGM, int WGN, int TM, int TN, int BK, bool PF>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
-    constexpr int KPT = IG_BK * BN / 256;             // gathered elements per thread per K step
-    constexpr int A_F4 = IG_BK * BM / 4;              // float4 per A tile
+    constexpr int KPT = BK * BN / 256;             // gathered elements per thread per K step
+    constexpr int A_F4 = BK * BM / 4;              // float4 per A tile
     constexpr int A_PT = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4, "four waves");
     static_assert(BN % 64 == 0 && KPT >= 1, "column groups must be wave-aligned");
 
-    __shared__ __attribute__((aligned(16))) float As[2][IG_BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][IG_BK][BN];
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     const int zphase = blockIdx.z / p.ksplit, zsplit = blockIdx.z - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     const int wm = wid / WGN, wn = wid % WGN;
     const int HW = p.H * p.W;
     const int T = ph.T;
+    const int kstep_c = BK / T, kstep_t = BK - kstep_c * T;   // how (channel, tap) advance per K step
     const int TWs = ph.TW, tw_magic = ph.tw_magic, dy0 = ph.dy0, dys = ph.dys, dx0 = ph.dx0, dxs = ph.dxs;
 
     // ---- per-thread gather column (fixed for the whole K loop)
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     int ck = 0, cc = 0, ct = 0;     // running (k, channel, tap) of the address computation in progress
     unsigned cm = 0;
     auto calc_begin = [&](int k0) {      // k0 may run past the end of K: the prefetches of the last iterations
-        const int ka = k0 > ph.Kpad - IG_BK ? ph.Kpad - IG_BK : k0;   // A: re-read the final panel rows (in bounds)
+        const int ka = k0 > ph.Kpad - BK ? ph.Kpad - BK : k0;   // A: re-read the final panel rows (in bounds)
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             // out-of-panel columns load column 0 and are zeroed when the tile is stored
@@ -204,8 +206,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         ck = k0 + kgrp * KPT;       // B: k >= K masks the element (its channel index would be out of range)
         cc = gc; ct = gt; cm = 0;
         // advance the group's first (channel, tap) to the next K step without a division
-        gt += ph.kstep_t;
-        gc += ph.kstep_c;
+        gt += kstep_t;
+        gc += kstep_c;
         if (gt >= T) { gt -= T; ++gc; }
     };
     // activations: (c, t) is wave-uniform -> offset arithmetic runs on the scalar unit; masked elements read
@@ -252,21 +254,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask >> j) & 1u) ? breg[j] : 0.0f;
     };
 
-    const int total_steps = ph.Kpad / IG_BK;
+    const int total_steps = ph.Kpad / BK;
     const int per_split = (total_steps + p.ksplit - 1) / p.ksplit;
     const int step0 = zsplit * per_split;
     int nsteps = total_steps - step0;
     if (nsteps > per_split) nsteps = per_split;
     if (nsteps < 0) nsteps = 0;
     {
-        const int kfirst = step0 * IG_BK + kgrp * KPT;
+        const int kfirst = step0 * BK + kgrp * KPT;
         gc = kfirst / T;
         gt = kfirst - gc * T;
     }
     if (nsteps > 0) {
-        calc_addr(step0 * IG_BK);
+        calc_addr(step0 * BK);
         issue_loads();
-        calc_addr((step0 + 1) * IG_BK);
+        calc_addr((step0 + 1) * BK);
         store_tiles(0);
     }
     __syncthreads();
@@ -278,23 +280,33 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         // prefetches are redundant (clamped to the final panel rows, written to the idle buffer) but branch-free.
         issue_loads();
         __builtin_amdgcn_sched_barrier(0);
-        calc_begin((step0 + s + 2) * IG_BK);
-#pragma unroll
-        for (int k2 = 0; k2 < IG_BK / 2; ++k2) {
-            float a[TM], b[TN];
+        calc_begin((step0 + s + 2) * BK);
+        float fa[2][TM], fb[2][TN];
+        auto frag = [&](int k2, float (&a)[TM], float (&b)[TN]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[buf][k2 * 2 + lrow][(wm * TM + i) * 32 + lcol];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = Bs[buf][k2 * 2 + lrow][(wn * TN + j) * 32 + lcol];
+        };
+        if (PF) frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            const int cur = PF ? (k2 & 1) : 0;
+            if (PF) {
+                if (k2 + 1 < BK / 2) frag(k2 + 1, fa[cur ^ 1], fb[cur ^ 1]);   // in flight during this pair's MFMAs
+            } else {
+                frag(k2, fa[0], fb[0]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
             // a slice of the NEXT-next step's address arithmetic rides in the shadow of this k-pair's MFMAs (an fp32
             // 32x32x2 MFMA holds the matrix pipe for 64 cycles); the fence keeps the slices where they are put
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
-                if (j * (IG_BK / 2) / KPT == k2) calc_elem(j);
+                if (j * (BK / 2) / KPT == k2) calc_elem(j);
             __builtin_amdgcn_sched_barrier(0);
         }
         calc_end();
@@ -352,6 +364,24 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
     }
 }
 
+// Tuning knobs (read once): LOCATE_IGEMM_BK = 16 | 32, LOCATE_IGEMM_PF = 0 | 1.
+static int igemm_bk() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("LOCATE_IGEMM_BK");
+        v = (e && atoi(e) == 16) ? 16 : 32;
+    }
+    return v;
+}
+static int igemm_pf() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LOCATE_IGEMM_PF");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v;
+}
+
 static int pick_bm(int M) {
     const int cands[4] = {128, 96, 64, 32};
     int best = 128, best_pad = 1 << 30;
@@ -368,7 +398,7 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     const int bm = pick_bm(M);
     const long long tiles = (long long)((nmax + 127) / 128) * ((M + bm - 1) / bm) * nphase;
     if (tiles >= 384) return 1;
-    const int steps = min_kpad / IG_BK;
+    const int steps = min_kpad / igemm_bk();
     long long want = (768 + tiles - 1) / tiles;
     const int max_split = steps / 8 > 0 ? steps / 8 : 1;      // at least 8 K steps (128 reduction elements) per block
     if (want > max_split) want = max_split;
@@ -385,14 +415,23 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     p.slab_stride = (long long)p.B * p.M * p.OH * p.OW;
     if (p.ksplit > 1) {
         for (int i = 0; i < p.nphase; ++i)   // phases with fewer K steps than splits would leave slab tiles unwritten
-            if (p.ph[i].Kpad / IG_BK < p.ksplit) p.ksplit = p.ph[i].Kpad / IG_BK;
+            if (p.ph[i].Kpad / igemm_bk() < p.ksplit) p.ksplit = p.ph[i].Kpad / igemm_bk();
         if (p.ksplit < 1) p.ksplit = 1;
     }
     dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
-    if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
-    else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
-    else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
-    else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+#define IG_LAUNCH(BKV, PFV)                                                                \
+    do {                                                                                    \
+        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, BKV, PFV><<<grid, 256, 0, st>>>(p);     \
+        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, BKV, PFV><<<grid, 256, 0, st>>>(p); \
+        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, BKV, PFV><<<grid, 256, 0, st>>>(p); \
+        else conv_igemm_kernel<1, 4, 1, 1, BKV, PFV><<<grid, 256, 0, st>>>(p);               \
+    } while (0)
+    const int bk = igemm_bk(), pf = igemm_pf();
+    if (bk == 32 && pf) IG_LAUNCH(32, true);
+    else if (bk == 32) IG_LAUNCH(32, false);
+    else if (pf) IG_LAUNCH(16, true);
+    else IG_LAUNCH(16, false);
+#undef IG_LAUNCH
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
@@ -424,7 +463,7 @@ static size_t slab_floats(const IgParams& p, int nmax) {
     int min_kpad = 1 << 30;
     for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
     int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
-    if (ks > min_kpad / IG_BK) ks = min_kpad / IG_BK;
+    if (ks > min_kpad / igemm_bk()) ks = min_kpad / igemm_bk();
     return ks > 1 ? (size_t)ks * p.B * p.M * p.OH * p.OW : 0;
 }
 
@@ -449,13 +488,12 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         pa.w = w; pa.out = panel;
         pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
         pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
-        pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_BK); pa.ld = round_up(g.M, 32);
+        pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_KPAD); pa.ld = round_up(g.M, 32);
         if (pack)
             if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
         IgPhase& ph = p.ph[0];
         ph.wp = panel; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
         ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
-        ph.kstep_c = IG_BK / ph.T; ph.kstep_t = IG_BK % ph.T;
         ph.TW = g.KW; ph.tw_magic = (65536 + g.KW - 1) / g.KW;
         ph.dy0 = -g.pad_h; ph.dys = 1; ph.dx0 = -g.pad_w; ph.dxs = 1;
         off = (size_t)pa.Kpad * pa.ld;
@@ -476,13 +514,12 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 pa.w = w; pa.out = panel ? panel + off : nullptr;
                 pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
                 pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
-                pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_BK); pa.ld = round_up(g.C, 32);
+                pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD); pa.ld = round_up(g.C, 32);
                 if (pack)
                     if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
                 ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
                 ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
-                ph.kstep_c = IG_BK / ph.T; ph.kstep_t = IG_BK % ph.T;
-                ph.TW = TW > 0 ? TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
+                        ph.TW = TW > 0 ? TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
                 ph.dy0 = dy0; ph.dys = -1; ph.dx0 = dx0; ph.dxs = -1;
                 off += (size_t)pa.Kpad * pa.ld;
                 const int nph = g.B * QH * QW;
