@@ -22,6 +22,7 @@
 // LDS with register prefetch of the next K step, one barrier per step.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -178,9 +179,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float breg[KPT];
-    float4 areg[A_PT];
-    unsigned bmask = 0;    // validity bits of breg[]; applied when the tile is written to LDS
+    // TWO register stages: the loads of K step s+2 are issued while step s is being multiplied (a full MFMA block is
+    // ~1 us; a panel row that misses L2 takes longer than that to arrive from the Infinity Cache / HBM, so a single
+    // stage in flight left every wave parked on vmcnt once per step - measured MFMA utilisation 53 %)
+    float breg[2][KPT];
+    float4 areg[2][A_PT];
+    unsigned bmask[2] = {0u, 0u};    // validity bits of breg[]; applied when the tile is written to LDS
     int gc = 0, gt = 0;    // (channel, tap) of this wave's first gathered row at the next address computation
 
     // Addresses of one K step's global loads.  They are computed ONE STEP AHEAD of the loads that use them, so the
@@ -231,27 +235,29 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         for (int j = 0; j < KPT; ++j) calc_elem(j);
         calc_end();
     };
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](auto RS) {
+        constexpr int rs = decltype(RS)::value;
 #pragma unroll
-        for (int i = 0; i < A_PT; ++i) areg[i] = *aaddr[i];
+        for (int i = 0; i < A_PT; ++i) areg[rs][i] = *aaddr[i];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) breg[j] = *baddr[j];
-        bmask = amask_next;
+        for (int j = 0; j < KPT; ++j) breg[rs][j] = *baddr[j];
+        bmask[rs] = amask_next;
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto RS, int buf) {
+        constexpr int rs = decltype(RS)::value;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             const int idx = tid + i * 256;
             if ((i + 1) * 256 <= A_F4 || idx < A_F4) {
                 const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
                 const bool ok = m0 + c4 * 4 < ph.ld;
-                float4 v = areg[i];
+                float4 v = areg[rs][i];
                 v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
                 *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = v;
             }
         }
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask >> j) & 1u) ? breg[j] : 0.0f;
+        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask[rs] >> j) & 1u) ? breg[rs][j] : 0.0f;
     };
 
     const int total_steps = ph.Kpad / BK;
@@ -265,22 +271,28 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         gc = kfirst / T;
         gt = kfirst - gc * T;
     }
+    using RS0 = std::integral_constant<int, 0>;
+    using RS1 = std::integral_constant<int, 1>;
     if (nsteps > 0) {
         calc_addr(step0 * BK);
-        issue_loads();
+        issue_loads(RS0{});                 // step 0
         calc_addr((step0 + 1) * BK);
-        store_tiles(0);
+        issue_loads(RS1{});                 // step 1
+        calc_addr((step0 + 2) * BK);        // addresses of step 2, consumed by the first iteration
+        store_tiles(RS0{}, 0);
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
-    for (int s = 0; s < nsteps; ++s) {
+
+    // One iteration = one basic block: the loads of step s+2 first (pinned; into the register stage that was just
+    // drained), then the MFMAs of step s from LDS with the address arithmetic of step s+3 sliced in between, then the
+    // LDS writes of step s+1 (whose loads were issued one whole iteration ago), one barrier.  Prefetches past the
+    // end are redundant but branch-free (A re-reads the final panel rows, B elements are masked).
+    auto iteration = [&](int s, auto RS_LOAD, auto RS_STORE) {
         const int buf = s & 1;
-        // One basic block per iteration: loads of step s+1 first (pinned), then the MFMAs of step s with the address
-        // arithmetic of step s+2 free to interleave, then the LDS writes of step s+1.  On the last iterations the
-        // prefetches are redundant (clamped to the final panel rows, written to the idle buffer) but branch-free.
-        issue_loads();
+        issue_loads(RS_LOAD);
         __builtin_amdgcn_sched_barrier(0);
-        calc_begin((step0 + s + 2) * BK);
+        calc_begin((step0 + s + 3) * BK);
         float fa[2][TM], fb[2][TN];
         auto frag = [&](int k2, float (&a)[TM], float (&b)[TN]) {
 #pragma unroll
@@ -302,17 +314,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            // a slice of the NEXT-next step's address arithmetic rides in the shadow of this k-pair's MFMAs (an fp32
-            // 32x32x2 MFMA holds the matrix pipe for 64 cycles); the fence keeps the slices where they are put
+            // a slice of a later step's address arithmetic rides in the shadow of this k-pair's MFMAs (an fp32 32x32x2
+            // MFMA holds the matrix pipe for 64 cycles); the fence keeps the slices where they are put
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if (j * (BK / 2) / KPT == k2) calc_elem(j);
             __builtin_amdgcn_sched_barrier(0);
         }
         calc_end();
-        store_tiles(buf ^ 1);
+        store_tiles(RS_STORE, buf ^ 1);
         __syncthreads();
+    };
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        iteration(s, RS0{}, RS1{});
+        iteration(s + 1, RS1{}, RS0{});
     }
+    if (s < nsteps) iteration(s, RS0{}, RS1{});
 
     const float out_scale = p.scale ? p.scale[0] : 1.0f;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -369,7 +387,7 @@ static int igemm_bk() {
     static int v = 0;
     if (!v) {
         const char* e = getenv("LOCATE_IGEMM_BK");
-        v = (e && atoi(e) == 16) ? 16 : 32;
+        v = (e && atoi(e) == 32) ? 32 : 16;
     }
     return v;
 }
