@@ -26,9 +26,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define IG_KPAD 32          // panels are zero-padded to a multiple of this many K rows (covers BK = 16 and 32)
+#define IG_BK 16            // K elements per main-loop step
+#define IG_KPAD 32          // panels are zero-padded to a multiple of this many K rows
+#define IG_TAIL 48          // extra zero rows after Kpad: the branch-free prefetch of the last steps stays in bounds
 #define IG_MAXT 32
-#define IG_ALU_PER_MFMA 8
 
 struct ConvGeom {
     int B, C, H, W;            // input of R
@@ -52,35 +53,43 @@ static int geom_check(const ConvGeom& g, const char* who) {
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---------------------------------------------------------------------------------------------
-// weight packing
+// Weight panel of one phase (all sections in 4-byte units, one buffer):
+//   weights [rows][ld]   K-major, rows = Kpad + IG_TAIL, zero beyond K and beyond M
+//   koff    [rows]       int: offset of gathered row k = (c, t) inside one batch image of the gathered tensor,
+//                        c*H*W + dy(t)*W + dx(t)  (0 beyond K)
+//   ktap    [rows / 4]   bytes: tap index t of row k (31 beyond K: a tap that is never valid)
+// The offset table turns the gather's per-element mixed-radix arithmetic (~230 ALU instructions per K step, which
+// cost a quarter of the kernel's throughput) into two wave-uniform scalar loads per step.
 // ---------------------------------------------------------------------------------------------
 struct PackArgs {
     const float* w;       // [M, C, KH, KW]
-    float* out;           // [Kpad][ld]
+    float* out;           // phase panel
     int M, C, KH, KW;
     int mode;             // 0: rows k=(c,kh,kw), cols m          (R forward)
                           // 1: rows k=(m,th,tw), cols c, taps kh = kh0 + s*th, kw = kw0 + s*tw   (R data-adjoint phase)
     int kh0, kw0, s, TH, TW;
-    int K, Kpad, ld;
+    int K, rows, ld;
+    int gHW, gW, dy0, dys, dx0, dxs;   // geometry of the gathered tensor and of the tap grid
 };
 
+static inline size_t panel_floats(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
+
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
-    const int64_t total = (int64_t)a.Kpad * a.ld;
+    const int64_t total = (int64_t)a.rows * a.ld;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int T = a.TH * a.TW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int k = (int)(i / a.ld), col = (int)(i - (int64_t)k * a.ld);
         float v = 0.0f;
         if (k < a.K) {
             if (a.mode == 0) {
                 if (col < a.M) {
-                    const int taps = a.KH * a.KW;
-                    const int c = k / taps, t = k - c * taps;
-                    v = a.w[((int64_t)col * a.C + c) * taps + t];
+                    const int c = k / T, t = k - c * T;
+                    v = a.w[((int64_t)col * a.C + c) * T + t];
                 }
             } else {
                 if (col < a.C) {
-                    const int tt = a.TH * a.TW;
-                    const int m = k / tt, r = k - m * tt;
+                    const int m = k / T, r = k - m * T;
                     const int th = r / a.TW, tw = r - th * a.TW;
                     const int kh = a.kh0 + a.s * th, kw = a.kw0 + a.s * tw;
                     v = a.w[(((int64_t)m * a.C + col) * a.KH + kh) * a.KW + kw];
@@ -89,20 +98,34 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
         }
         a.out[i] = v;
     }
+    int* koff = reinterpret_cast<int*>(a.out + (size_t)a.rows * a.ld);
+    unsigned char* ktap = reinterpret_cast<unsigned char*>(koff + a.rows);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.rows; k += stride) {
+        int off = 0, tap = 31;
+        if (k < a.K && T > 0) {
+            const int c = (int)k / T, t = (int)k - c * T;
+            const int th = t / a.TW, tw = t - th * a.TW;
+            off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
+            tap = t;
+        }
+        koff[k] = off;
+        ktap[k] = (unsigned char)tap;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// implicit-GEMM gather kernel:  out[b, m, oy, ox] = sum_{c, t} wp[(c*T + t)][m] * in[b, c, qy*istride + dy[t], qx*istride + dx[t]]
-//   with (oy, ox) = (oy0 + qy*ostep, ox0 + qx*ostep), zero outside the input.
+// implicit-GEMM gather kernel:
+//   out[b, m, oy, ox] = scale * sum_k wp[k][m] * in[b, :, qy*istride, qx*istride][koff[k]]  (+ bias[m])
+//   with (oy, ox) = (oy0 + qy*ostep, ox0 + qx*ostep); taps that fall outside the input contribute zero.
 // ---------------------------------------------------------------------------------------------
 struct IgPhase {
-    const float* wp;   // packed weights [Kpad][ld]
+    const float* wp;             // packed weights [rows][ld]
+    const int* koff;             // [rows]
+    const unsigned char* ktap;   // [rows]
     int K, Kpad, ld, T;
     int oy0, ox0, QH, QW;
-    // taps form a TH x TW grid, tap t = th*TW + tw reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw):
-    // pure arithmetic on the scalar unit, no table lookups in the gather loop
-    int TW, tw_magic;            // th = (t * tw_magic) >> 16  (exact for t < 32)
-    int dy0, dys, dx0, dxs;
+    int TW, tw_magic;            // tap t = th*TW + tw, th = (t * tw_magic) >> 16  (exact for t < 32)
+    int dy0, dys, dx0, dxs;      // tap (th, tw) reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw)
 };
 
 struct IgParams {
@@ -120,16 +143,18 @@ struct IgParams {
     IgPhase ph[4];
 };
 
-// BK: K elements per step (16 or 32).  PF: prefetch the next k-pair's LDS fragments before the current MFMAs.
-template <int WGM, int WGN, int TM, int TN, int BK, bool PF>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
+    constexpr int BK = IG_BK;
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
-    constexpr int KPT = BK * BN / 256;             // gathered elements per thread per K step
-    constexpr int A_F4 = BK * BM / 4;              // float4 per A tile
+    constexpr int KPT = BK * BN / 256;                // gathered elements per thread per K step
+    constexpr int A_F4 = BK * BM / 4;                 // float4 per A tile
     constexpr int A_PT = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4, "four waves");
-    static_assert(BN % 64 == 0 && KPT >= 1, "column groups must be wave-aligned");
+    static_assert(BN % 64 == 0 && KPT == 8, "one 8-row group of the offset table per thread and step");
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
@@ -143,19 +168,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
-    const int HW = p.H * p.W;
     const int T = ph.T;
-    const int kstep_c = BK / T, kstep_t = BK - kstep_c * T;   // how (channel, tap) advance per K step
-    const int TWs = ph.TW, tw_magic = ph.tw_magic, dy0 = ph.dy0, dys = ph.dys, dx0 = ph.dx0, dxs = ph.dxs;
 
-    // ---- per-thread gather column (fixed for the whole K loop)
+    // ---- per-thread gather column (fixed for the whole K loop): base pointer and the set of taps inside the input
     const int ncol = tid % BN;
     const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform
     const int n = n0 + ncol;
-    const bool n_ok = n < N;
-    unsigned tapmask = 0;
+    unsigned tapmask = 0;    // bit t: tap t reads inside the input for this column (bit 31 is never set)
     const float* in_col = p.in;
     {
+        const bool n_ok = n < N;
         const int nn = n_ok ? n : 0;
         const int qhw = ph.QH * ph.QW;
         const int b = nn / qhw, q = nn - b * qhw;
@@ -171,6 +193,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
             }
         }
     }
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -179,162 +202,112 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // TWO register stages: the loads of K step s+2 are issued while step s is being multiplied (a full MFMA block is
-    // ~1 us; a panel row that misses L2 takes longer than that to arrive from the Infinity Cache / HBM, so a single
-    // stage in flight left every wave parked on vmcnt once per step - measured MFMA utilisation 53 %)
-    float breg[2][KPT];
-    float4 areg[2][A_PT];
-    unsigned bmask[2] = {0u, 0u};    // validity bits of breg[]; applied when the tile is written to LDS
-    int gc = 0, gt = 0;    // (channel, tap) of this wave's first gathered row at the next address computation
-
-    // Addresses of one K step's global loads.  They are computed ONE STEP AHEAD of the loads that use them, so the
-    // scalar/vector address arithmetic sits inside the MFMA block (where it is free) and the loads themselves are
-    // the first instructions of an iteration (a full MFMA block of latency cover).
-    const float* baddr[KPT];
-    const float4* aaddr[A_PT];
-    unsigned amask_next = 0;
-
-    int ck = 0, cc = 0, ct = 0;     // running (k, channel, tap) of the address computation in progress
-    unsigned cm = 0;
-    auto calc_begin = [&](int k0) {      // k0 may run past the end of K: the prefetches of the last iterations
-        const int ka = k0 > ph.Kpad - BK ? ph.Kpad - BK : k0;   // A: re-read the final panel rows (in bounds)
-#pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            // out-of-panel columns load column 0 and are zeroed when the tile is stored
-            const int idx = tid + i * 256;
-            const int idc = ((i + 1) * 256 <= A_F4 || idx < A_F4) ? idx : 0;
-            const int row = idc / (BM / 4), c4 = idc - row * (BM / 4);
-            const int col = m0 + c4 * 4;
-            aaddr[i] = reinterpret_cast<const float4*>(ph.wp + (long long)(ka + row) * ph.ld + (col < ph.ld ? col : 0));
-        }
-        ck = k0 + kgrp * KPT;       // B: k >= K masks the element (its channel index would be out of range)
-        cc = gc; ct = gt; cm = 0;
-        // advance the group's first (channel, tap) to the next K step without a division
-        gt += kstep_t;
-        gc += kstep_c;
-        if (gt >= T) { gt -= T; ++gc; }
-    };
-    // activations: (c, t) is wave-uniform -> offset arithmetic runs on the scalar unit; masked elements read
-    // element 0 of the column (always mapped) and are zeroed by a select at store time, so the loads carry no
-    // exec-mask branches and all KPT of them are in flight together
-    auto calc_elem = [&](int j) {
-        const int ts = __builtin_amdgcn_readfirstlane(ct);
-        const int cs = __builtin_amdgcn_readfirstlane(cc);
-        const int th = (ts * tw_magic) >> 16, tw = ts - th * TWs;
-        const int off = cs * HW + (dy0 + dys * th) * p.W + dx0 + dxs * tw;
-        const bool valid = ck < ph.K && ((tapmask >> ts) & 1u);
-        baddr[j] = in_col + (valid ? off : 0);
-        cm |= (valid ? 1u : 0u) << j;
-        ++ck; ++ct;
-        if (ct == T) { ct = 0; ++cc; }
-    };
-    auto calc_end = [&]() { amask_next = cm; };
-    auto calc_addr = [&](int k0) {
-        calc_begin(k0);
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) calc_elem(j);
-        calc_end();
-    };
-    auto issue_loads = [&](auto RS) {
-        constexpr int rs = decltype(RS)::value;
-#pragma unroll
-        for (int i = 0; i < A_PT; ++i) areg[rs][i] = *aaddr[i];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) breg[rs][j] = *baddr[j];
-        bmask[rs] = amask_next;
-    };
-    auto store_tiles = [&](auto RS, int buf) {
-        constexpr int rs = decltype(RS)::value;
-#pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            const int idx = tid + i * 256;
-            if ((i + 1) * 256 <= A_F4 || idx < A_F4) {
-                const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
-                const bool ok = m0 + c4 * 4 < ph.ld;
-                float4 v = areg[rs][i];
-                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-                *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = v;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask[rs] >> j) & 1u) ? breg[rs][j] : 0.0f;
-    };
-
+    // ---- K range of this block (split-K) and the running addresses of its prefetch
     const int total_steps = ph.Kpad / BK;
     const int per_split = (total_steps + p.ksplit - 1) / p.ksplit;
     const int step0 = zsplit * per_split;
     int nsteps = total_steps - step0;
     if (nsteps > per_split) nsteps = per_split;
     if (nsteps < 0) nsteps = 0;
-    {
-        const int kfirst = step0 * BK + kgrp * KPT;
-        gc = kfirst / T;
-        gt = kfirst - gc * T;
+
+    const float4* aptr[A_PT];      // weight-panel rows: advance BK rows per step; the panel has IG_TAIL spare rows
+    bool a_ok[A_PT];
+    int a_row[A_PT], a_c4[A_PT];
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+        const int idx = tid + i * 256;
+        const int idc = ((i + 1) * 256 <= A_F4 || idx < A_F4) ? idx : 0;
+        a_row[i] = idc / (BM / 4);
+        a_c4[i] = idc - a_row[i] * (BM / 4);
+        const int col = m0 + a_c4[i] * 4;
+        a_ok[i] = col < ph.ld;
+        aptr[i] = reinterpret_cast<const float4*>(ph.wp + (long long)(step0 * BK + a_row[i]) * ph.ld + (a_ok[i] ? col : 0));
     }
-    using RS0 = std::integral_constant<int, 0>;
-    using RS1 = std::integral_constant<int, 1>;
+    const long long a_step = (long long)BK * ph.ld / 4;            // float4 units
+    int kidx = step0 * BK + kgrp * KPT;                           // wave-uniform first table row of the next load
+
+    float breg[KPT];
+    float4 areg[A_PT];
+    unsigned bmask = 0;      // validity bits of breg[]; applied when the tile is written to LDS (the loads themselves
+                             // are unconditional: masked elements read element 0 of the column)
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            areg[i] = *aptr[i];
+            aptr[i] += a_step;
+        }
+        const int ks = __builtin_amdgcn_readfirstlane(kidx);
+        const i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + ks);                      // s_load_dwordx8
+        const unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + ks);   // s_load_dwordx2
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const unsigned tap = (unsigned)(taps >> (8 * j)) & 31u;
+            const bool valid = (tapmask >> tap) & 1u;
+            breg[j] = in_col[valid ? offs[j] : 0];
+            m |= (valid ? 1u : 0u) << j;
+        }
+        bmask = m;
+        kidx += BK;
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int idx = tid + i * 256;
+            if ((i + 1) * 256 <= A_F4 || idx < A_F4) {
+                float4 v = areg[i];
+                v.x = a_ok[i] ? v.x : 0.f; v.y = a_ok[i] ? v.y : 0.f; v.z = a_ok[i] ? v.z : 0.f; v.w = a_ok[i] ? v.w : 0.f;
+                *reinterpret_cast<float4*>(&As[buf][a_row[i]][a_c4[i] * 4]) = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask >> j) & 1u) ? breg[j] : 0.0f;
+    };
+
     if (nsteps > 0) {
-        calc_addr(step0 * BK);
-        issue_loads(RS0{});                 // step 0
-        calc_addr((step0 + 1) * BK);
-        issue_loads(RS1{});                 // step 1
-        calc_addr((step0 + 2) * BK);        // addresses of step 2, consumed by the first iteration
-        store_tiles(RS0{}, 0);
+        issue_loads();
+        store_tiles(0);
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
-
-    // One iteration = one basic block: the loads of step s+2 first (pinned; into the register stage that was just
-    // drained), then the MFMAs of step s from LDS with the address arithmetic of step s+3 sliced in between, then the
-    // LDS writes of step s+1 (whose loads were issued one whole iteration ago), one barrier.  Prefetches past the
-    // end are redundant but branch-free (A re-reads the final panel rows, B elements are masked).
-    auto iteration = [&](int s, auto RS_LOAD, auto RS_STORE) {
+    for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        issue_loads(RS_LOAD);
+        // One basic block per iteration: the loads of step s+1 first (pinned by the fence), the MFMAs of step s, the
+        // LDS writes of step s+1, one barrier.  The last iteration's prefetch is redundant but branch-free (zero tail
+        // rows of the panel and of the offset table).
+        issue_loads();
         __builtin_amdgcn_sched_barrier(0);
-        calc_begin((step0 + s + 3) * BK);
-        float fa[2][TM], fb[2][TN];
-        auto frag = [&](int k2, float (&a)[TM], float (&b)[TN]) {
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[buf][k2 * 2 + lrow][(wm * TM + i) * 32 + lcol];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = Bs[buf][k2 * 2 + lrow][(wn * TN + j) * 32 + lcol];
-        };
-        if (PF) frag(0, fa[0], fb[0]);
-#pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
-            const int cur = PF ? (k2 & 1) : 0;
-            if (PF) {
-                if (k2 + 1 < BK / 2) frag(k2 + 1, fa[cur ^ 1], fb[cur ^ 1]);   // in flight during this pair's MFMAs
-            } else {
-                frag(k2, fa[0], fb[0]);
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            // a slice of a later step's address arithmetic rides in the shadow of this k-pair's MFMAs (an fp32 32x32x2
-            // MFMA holds the matrix pipe for 64 cycles); the fence keeps the slices where they are put
-#pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                if (j * (BK / 2) / KPT == k2) calc_elem(j);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        calc_end();
-        store_tiles(RS_STORE, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
         __syncthreads();
-    };
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        iteration(s, RS0{}, RS1{});
-        iteration(s + 1, RS1{}, RS0{});
     }
-    if (s < nsteps) iteration(s, RS0{}, RS1{});
 
     const float out_scale = p.scale ? p.scale[0] : 1.0f;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
+    const bool split = p.ksplit > 1;
+    float bias_v[TM][16];          // this lane's 16 rows per row-tile: loaded once, all loads in flight together
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            const bool use = p.bias != nullptr && !split && m < p.M;
+            const float* bp = use ? p.bias + m : p.in;          // always a valid address; value discarded when unused
+            bias_v[i][r] = use ? *bp : 0.0f;
+        }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nj = n0 + (wn * TN + j) * 32 + lcol;
@@ -343,7 +316,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         const int b = nj / qhw, q = nj - b * qhw;
         const int qy = q / ph.QW, qx = q - qy * ph.QW;
         const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
-        const bool split = p.ksplit > 1;
         float* optr = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
                             : p.out + (long long)b * p.out_bs + pix;
 #pragma unroll
@@ -351,20 +323,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (!split) {
-                        v *= out_scale;
-                        if (p.bias) v += p.bias[m];
-                    }
-                    optr[(long long)m * plane] = v;
-                }
+                if (m < p.M) optr[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], out_scale, bias_v[i][r]);
             }
         }
     }
 }
 
-// out[b, m, :] = bias[m] + sum_z slab[z][b, m, :]
+// out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 int B, int M, int plane,
@@ -380,24 +345,6 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
         if (bias) acc += bias[(int)(r / plane)];
         out[b * out_bs + r] = acc;
     }
-}
-
-// Tuning knobs (read once): LOCATE_IGEMM_BK = 16 | 32, LOCATE_IGEMM_PF = 0 | 1.
-static int igemm_bk() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("LOCATE_IGEMM_BK");
-        v = (e && atoi(e) == 32) ? 32 : 16;
-    }
-    return v;
-}
-static int igemm_pf() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LOCATE_IGEMM_PF");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v;
 }
 
 static int pick_bm(int M) {
@@ -416,7 +363,7 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     const int bm = pick_bm(M);
     const long long tiles = (long long)((nmax + 127) / 128) * ((M + bm - 1) / bm) * nphase;
     if (tiles >= 384) return 1;
-    const int steps = min_kpad / igemm_bk();
+    const int steps = min_kpad / IG_BK;
     long long want = (768 + tiles - 1) / tiles;
     const int max_split = steps / 8 > 0 ? steps / 8 : 1;      // at least 8 K steps (128 reduction elements) per block
     if (want > max_split) want = max_split;
@@ -431,25 +378,13 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     p.ksplit = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
     p.slab = static_cast<float*>(slab_ws);
     p.slab_stride = (long long)p.B * p.M * p.OH * p.OW;
-    if (p.ksplit > 1) {
-        for (int i = 0; i < p.nphase; ++i)   // phases with fewer K steps than splits would leave slab tiles unwritten
-            if (p.ph[i].Kpad / igemm_bk() < p.ksplit) p.ksplit = p.ph[i].Kpad / igemm_bk();
-        if (p.ksplit < 1) p.ksplit = 1;
-    }
+    if (p.ksplit > min_kpad / IG_BK) p.ksplit = min_kpad / IG_BK;
+    if (p.ksplit < 1) p.ksplit = 1;
     dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
-#define IG_LAUNCH(BKV, PFV)                                                                \
-    do {                                                                                    \
-        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, BKV, PFV><<<grid, 256, 0, st>>>(p);     \
-        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, BKV, PFV><<<grid, 256, 0, st>>>(p); \
-        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, BKV, PFV><<<grid, 256, 0, st>>>(p); \
-        else conv_igemm_kernel<1, 4, 1, 1, BKV, PFV><<<grid, 256, 0, st>>>(p);               \
-    } while (0)
-    const int bk = igemm_bk(), pf = igemm_pf();
-    if (bk == 32 && pf) IG_LAUNCH(32, true);
-    else if (bk == 32) IG_LAUNCH(32, false);
-    else if (pf) IG_LAUNCH(16, true);
-    else IG_LAUNCH(16, false);
-#undef IG_LAUNCH
+    if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+    else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+    else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+    else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
@@ -461,7 +396,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
 }
 
 static int launch_pack(const PackArgs& a, hipStream_t st, const char* who) {
-    pack_weights_kernel<<<stream_grid((int64_t)a.Kpad * a.ld, 256), 256, 0, st>>>(a);
+    pack_weights_kernel<<<stream_grid((int64_t)a.rows * a.ld, 256), 256, 0, st>>>(a);
     LOCATE_LAUNCH_CHECK(who);
     return LOCATE_OK;
 }
@@ -481,7 +416,7 @@ static size_t slab_floats(const IgParams& p, int nmax) {
     int min_kpad = 1 << 30;
     for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
     int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
-    if (ks > min_kpad / igemm_bk()) ks = min_kpad / igemm_bk();
+    if (ks > min_kpad / IG_BK) ks = min_kpad / IG_BK;
     return ks > 1 ? (size_t)ks * p.B * p.M * p.OH * p.OW : 0;
 }
 
@@ -491,11 +426,20 @@ static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int*
     *T = *k0 < K ? (K - *k0 + s - 1) / s : 0;
 }
 
+static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
+    ph.wp = panel_base;
+    ph.koff = reinterpret_cast<const int*>(panel_base + (size_t)pa.rows * pa.ld);
+    ph.ktap = reinterpret_cast<const unsigned char*>(ph.koff + pa.rows);
+    ph.K = pa.K; ph.Kpad = pa.rows - IG_TAIL; ph.ld = pa.ld;
+    ph.TW = pa.TW > 0 ? pa.TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
+    ph.dy0 = pa.dy0; ph.dys = pa.dys; ph.dx0 = pa.dx0; ph.dxs = pa.dxs;
+}
+
 // Fills the phase table of R (adjoint = 0) or of its data adjoint (adjoint = 1: one phase per sub-pixel).
 // `panel` is the packed-weight buffer (may be null when only sizes are wanted); with `pack` the packing kernels
 // are launched.  Returns the panel size in floats and the largest per-phase N.
 static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* panel, IgParams& p, int* nmax_out,
-                     size_t* panel_floats, bool pack, hipStream_t st) {
+                     size_t* panel_floats_out, bool pack, hipStream_t st) {
     size_t off = 0;
     int nmax = 0;
     p.nphase = 0;
@@ -506,15 +450,15 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         pa.w = w; pa.out = panel;
         pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
         pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
-        pa.K = g.C * g.KH * g.KW; pa.Kpad = round_up(pa.K, IG_KPAD); pa.ld = round_up(g.M, 32);
+        pa.K = g.C * g.KH * g.KW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
+        pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = -g.pad_h; pa.dys = 1; pa.dx0 = -g.pad_w; pa.dxs = 1;
         if (pack)
             if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
         IgPhase& ph = p.ph[0];
-        ph.wp = panel; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = g.KH * g.KW;
+        phase_finish(ph, pa, panel);
+        ph.T = g.KH * g.KW;
         ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
-        ph.TW = g.KW; ph.tw_magic = (65536 + g.KW - 1) / g.KW;
-        ph.dy0 = -g.pad_h; ph.dys = 1; ph.dx0 = -g.pad_w; ph.dxs = 1;
-        off = (size_t)pa.Kpad * pa.ld;
+        off = panel_floats(pa.rows, pa.ld);
         nmax = g.B * g.OH * g.OW;
     } else {
         p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
@@ -532,20 +476,20 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 pa.w = w; pa.out = panel ? panel + off : nullptr;
                 pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 1;
                 pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
-                pa.K = g.M * TH * TW; pa.Kpad = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD); pa.ld = round_up(g.C, 32);
+                pa.K = g.M * TH * TW; pa.rows = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.C, 32);
+                pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
                 if (pack)
                     if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
-                ph.wp = pa.out; ph.K = pa.K; ph.Kpad = pa.Kpad; ph.ld = pa.ld; ph.T = TH * TW > 0 ? TH * TW : 1;
+                phase_finish(ph, pa, pa.out);
+                ph.T = TH * TW;
                 ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
-                        ph.TW = TW > 0 ? TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
-                ph.dy0 = dy0; ph.dys = -1; ph.dx0 = dx0; ph.dxs = -1;
-                off += (size_t)pa.Kpad * pa.ld;
+                off += panel_floats(pa.rows, pa.ld);
                 const int nph = g.B * QH * QW;
                 if (nph > nmax) nmax = nph;
             }
     }
     if (nmax_out) *nmax_out = nmax;
-    if (panel_floats) *panel_floats = off;
+    if (panel_floats_out) *panel_floats_out = off;
     return LOCATE_OK;
 }
 
@@ -557,9 +501,9 @@ LOCATE_API size_t locate_conv_panel_bytes(const int* geom, int adjoint) {
     return n * sizeof(float);
 }
 
-// Re-lays W [M, C, KH, KW] out as the K-major, zero-padded panel(s) the implicit GEMM streams.  Only needs to be
-// redone when W changes (once per optimizer step), not per forward: the spectral-norm 1/sigma is applied in the
-// GEMM epilogue instead of being baked into the weights.
+// Re-lays W [M, C, KH, KW] out as the K-major, zero-padded panel(s) the implicit GEMM streams, followed by the
+// gather offset table of this geometry.  Only needs to be redone when W changes (once per optimizer step), not per
+// forward: the spectral-norm 1/sigma is applied in the GEMM epilogue instead of being baked into the weights.
 LOCATE_API int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* panel, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_pack_panel")) return e;
