@@ -298,32 +298,37 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
     const bool split = p.ksplit > 1;
-    float bias_v[TM][16];          // this lane's 16 rows per row-tile: loaded once, all loads in flight together
+    const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int nj = n0 + (wn * TN + j) * 32 + lcol;
+        const int nn = nj < N ? nj : 0;
+        const int qhw = ph.QH * ph.QW;
+        const int b = nn / qhw, q = nn - b * qhw;
+        const int qy = q / ph.QW, qx = q - qy * ph.QW;
+        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
+        const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
+                               : p.out + (long long)b * p.out_bs + pix;
+        optr[j] = nj < N ? o : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float bias_v[16];          // this lane's 16 rows of the row tile: loaded together, branch-free
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             const bool use = p.bias != nullptr && !split && m < p.M;
             const float* bp = use ? p.bias + m : p.in;          // always a valid address; value discarded when unused
-            bias_v[i][r] = use ? *bp : 0.0f;
+            bias_v[r] = use ? *bp : 0.0f;
         }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nj = n0 + (wn * TN + j) * 32 + lcol;
-        if (nj >= N) continue;
-        const int qhw = ph.QH * ph.QW;
-        const int b = nj / qhw, q = nj - b * qhw;
-        const int qy = q / ph.QW, qx = q - qy * ph.QW;
-        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
-        float* optr = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
-                            : p.out + (long long)b * p.out_bs + pix;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
+            float* o = const_cast<float*>(optr[j]);
+            if (o == nullptr) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) optr[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], out_scale, bias_v[i][r]);
+                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], out_scale, bias_v[r]);
             }
         }
     }
@@ -362,7 +367,8 @@ static int pick_bm(int M) {
 static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     const int bm = pick_bm(M);
     const long long tiles = (long long)((nmax + 127) / 128) * ((M + bm - 1) / bm) * nphase;
-    if (tiles >= 384) return 1;
+    // 256 CUs x ~3 resident blocks: launches of >= 768 blocks, or an exact multiple of 256 from 512 up, are balanced
+    if (tiles >= 768 || (tiles >= 512 && tiles % 256 == 0)) return 1;
     const int steps = min_kpad / IG_BK;
     long long want = (768 + tiles - 1) / tiles;
     const int max_split = steps / 8 > 0 ? steps / 8 : 1;      // at least 8 K steps (128 reduction elements) per block
@@ -573,7 +579,22 @@ struct WgParams {
     int R;              // C * KH * KW
     int N;              // B * OH * OW
     int chunk;          // reduction elements per split (multiple of WG_BK)
+    unsigned q_mul, ow_mul;   // division by Q = OH*OW and by OW as multiply-high + shifts (see fastdiv)
+    int q_s1, q_s2, ow_s1, ow_s2;
 };
+
+// n / d for 0 <= n < 2^31 as t = mulhi(n, mul); (t + ((n - t) >> s1)) >> s2   (Granlund-Montgomery)
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, int s1, int s2) {
+    const unsigned t = __umulhi((unsigned)n, mul);
+    return (int)((t + (((unsigned)n - t) >> s1)) >> s2);
+}
+static void fastdiv_make(unsigned d, unsigned* mul, int* s1, int* s2) {
+    if (d <= 1) { *mul = 0; *s1 = 0; *s2 = 0; return; }
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *s1 = 1; *s2 = l - 1;
+}
 
 template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
@@ -624,12 +645,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     float greg[G_PT], xreg[X_PT];
     unsigned gmask = 0, xmask = 0;   // validity bits, applied when the tiles are written to LDS (loads are unconditional
                                      // from clamped addresses so that they all issue back to back, see conv_igemm_kernel)
+    // per-thread invariants of the gathered operand: this thread always loads the same X_PT im2col columns
+    int xoff[X_PT], xdyx[X_PT];
+#pragma unroll
+    for (int i = 0; i < X_PT; ++i) {
+        const int rl = sub + 8 * i;
+        xoff[i] = rt_off[rl];
+        xdyx[i] = ((int)rt_dy[rl] & 0xffff) | ((int)rt_dx[rl] << 16);
+    }
     auto load_tiles = [&](int nb) {
         const int n = nb + nl;
         const bool ok = n < n_end;
         const int nn = ok ? n : 0;
-        const int b = nn / Q, q = nn - b * Q;
-        const int oh = q / p.OW, ow = q - oh * p.OW;
+        const int b = fastdiv(nn, p.q_mul, p.q_s1, p.q_s2), q = nn - b * Q;
+        const int oh = fastdiv(q, p.ow_mul, p.ow_s1, p.ow_s2), ow = q - oh * p.OW;
         const float* gp = p.gy + (long long)b * p.gy_bs + q;
         gmask = 0;
 #pragma unroll
@@ -640,15 +669,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
             gmask |= (v ? 1u : 0u) << i;
         }
         const int iy0 = oh * p.stride, ix0 = ow * p.stride;
-        const float* xp = p.x + (long long)b * p.x_bs + (long long)iy0 * p.W + ix0;
+        const int base = iy0 * p.W + ix0;
+        const float* xp = p.x + (long long)b * p.x_bs;       // start of batch image b
         xmask = 0;
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
-            const int rl = sub + 8 * i;
-            const int off = rt_off[rl];
-            const bool v = ok && off != (-2147483647 - 1) && (unsigned)(iy0 + rt_dy[rl]) < (unsigned)p.H &&
-                           (unsigned)(ix0 + rt_dx[rl]) < (unsigned)p.W;
-            xreg[i] = xp[v ? off : -(iy0 * p.W + ix0)];   // masked lanes read element 0 of the batch image (always valid)
+            const int dy = (short)(xdyx[i] & 0xffff), dx = xdyx[i] >> 16;
+            const bool v = ok && xoff[i] != (-2147483647 - 1) && (unsigned)(iy0 + dy) < (unsigned)p.H &&
+                           (unsigned)(ix0 + dx) < (unsigned)p.W;
+            xreg[i] = xp[v ? base + xoff[i] : 0];            // masked lanes read element 0 of the image (always valid)
             xmask |= (v ? 1u : 0u) << i;
         }
     };
@@ -747,6 +776,8 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW; p.KH = g.KH; p.KW = g.KW;
     p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.R = g.C * g.KH * g.KW; p.N = g.B * g.OH * g.OW; p.chunk = chunk;
+    fastdiv_make((unsigned)(g.OH * g.OW), &p.q_mul, &p.q_s1, &p.q_s2);
+    fastdiv_make((unsigned)g.OW, &p.ow_mul, &p.ow_s1, &p.ow_s2);
     dim3 grid((p.R + 127) / 128, (g.M + bm - 1) / bm, nsplit);
     if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
     else if (bm == 96) conv_wgrad_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
