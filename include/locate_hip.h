@@ -82,11 +82,13 @@ int locate_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
  * int h, wd, nchunk, pad} (locate_sn_table_record_bytes() each), scratch t[wd], s[h], tpart[ceil(h/64)*wd] */
 size_t locate_sn_table_record_bytes(void);
 int locate_sn_power_iter_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream);
-/* dW_bar = g/sigma + dsigma u v^T, du = dsigma (W v), dv = dsigma W^T u with dsigma = -<g, W_bar>/sigma^2;
- * u, v are the CURRENT state (the reference's autograd sees the latest .data); du, dv nullable */
+/* after locate_conv_wgrad(.., w_ref = W_bar, inv_scale = 1/sigma, inner_partial): gw (in/out) enters as G/sigma and
+ * leaves as dW_bar = G/sigma + dsigma u v^T; du = dsigma (W v), dv = dsigma W^T u with dsigma = -<G, W_bar>/sigma^2;
+ * u, v are the CURRENT state (the reference's autograd sees the latest .data); du, dv nullable; w only needed for dv */
 size_t locate_sn_bwd_workspace_bytes(int h, int wd);
-int locate_sn_weight_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma, const float* wv,
-                         float* dw, float* du, float* dv, int h, int wd, void* workspace, void* stream);
+int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* w, const float* u, const float* v,
+                         const float* sigma, const float* wv, float* gw, float* du, float* dv, int h, int wd,
+                         void* workspace, void* stream);
 
 /* ---- dense contractions as implicit GEMMs on the fp32 MFMA (libs/conv.py:14-20, libs/attention.py:18-46,
  *      libs/scale.py:25-34, libs/linear.py:10).  geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW}
@@ -103,10 +105,13 @@ int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* 
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale, const float* bias,
                       float* gx, int64_t gx_bs, void* workspace, void* stream);
-/* gw[m,c,kh,kw] = sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction) */
+/* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
+ * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
+ * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable. */
 size_t locate_conv_wgrad_workspace_bytes(const int* geom);
+int locate_conv_wgrad_partials(const int* geom);
 int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
-                      void* workspace, void* stream);
+                      const float* w_ref, const float* inv_scale, double* inner_partial, void* workspace, void* stream);
 
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */

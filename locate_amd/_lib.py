@@ -51,7 +51,7 @@ PROTOTYPES = {
     "locate_sn_table_record_bytes": (c_sz, []),
     "locate_sn_power_iter_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_sn_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
-    "locate_sn_weight_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "locate_sn_weight_bwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "locate_conv_panel_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
@@ -59,7 +59,8 @@ PROTOTYPES = {
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p]),
+    "locate_conv_wgrad_partials": (c_i, [c_ip]),
+    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
     "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),

@@ -581,6 +581,11 @@ struct WgParams {
     int chunk;          // reduction elements per split (multiple of WG_BK)
     unsigned q_mul, ow_mul;   // division by Q = OH*OW and by OW as multiply-high + shifts (see fastdiv)
     int q_s1, q_s2, ow_s1, ow_s2;
+    // single-split launches finish in the epilogue (no slab, no reduce kernel):
+    float* direct_out;        // gw, or null when slabs are used
+    const float* w_ref;       // W_bar for the fused <G, W_bar> partial sums (nullable)
+    const float* inv_scale;   // device scalar 1/sigma (nullable)
+    double* partial;          // one double per block (nullable)
 };
 
 // n / d for 0 <= n < 2^31 as t = mulhi(n, mul); (t + ((n - t) >> s1)) >> s2   (Granlund-Montgomery)
@@ -714,7 +719,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         __syncthreads();
     }
 
-    float* slab = p.slab + (long long)blockIdx.z * p.M * p.R;
+    // epilogue.  With a single split the result is final: scale by 1/sigma, write the gradient in the weight's own
+    // layout and reduce this block's share of <G, W_bar> (spectral-norm backward needs it) - no slab round trip.
+    __shared__ double red[4];
+    const bool direct = p.direct_out != nullptr;
+    float* dst = direct ? p.direct_out : p.slab + (long long)blockIdx.z * p.M * p.R;
+    const float sc = (direct && p.inv_scale) ? p.inv_scale[0] : 1.0f;
+    double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + lcol;
@@ -724,27 +735,48 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
-                if (m < p.M) slab[(long long)m * p.R + r] = acc[i][j][e];
+                if (m < p.M) {
+                    const long long idx = (long long)m * p.R + r;
+                    const float v = acc[i][j][e];
+                    if (direct && p.w_ref) dot += (double)v * (double)p.w_ref[idx];
+                    dst[idx] = v * sc;
+                }
             }
+    }
+    if (direct && p.partial) {
+        dot = wave_sum_d(dot);
+        if (lane == 0) red[wid] = dot;
+        __syncthreads();
+        if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
+// out = (sum_z slab[z]) * inv_scale;  partial[block] = this block's share of <sum_z slab[z], w_ref>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
-                                                          int nsplit) {
+                                                          int nsplit, const float* __restrict__ w_ref,
+                                                          const float* __restrict__ inv_scale, double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    const float sc = inv_scale ? inv_scale[0] : 1.0f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double dot = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float acc = 0.0f;
         for (int z = 0; z < nsplit; ++z) acc += slab[(int64_t)z * n + i];
-        out[i] = acc;
+        if (w_ref) dot += (double)acc * (double)w_ref[i];
+        out[i] = acc * sc;
+    }
+    if (partial) {
+        dot = block_sum<double>(dot, scratch);
+        if (threadIdx.x == 0) partial[blockIdx.x] = dot;
     }
 }
 
-static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk) {
+static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int* tiles_out) {
     *bm = pick_bm(g.M);
     const int R = g.C * g.KH * g.KW;
     const int64_t N = (int64_t)g.B * g.OH * g.OW;
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
-    int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks (256 CUs x 4)
+    int64_t want = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;      // fill 256 CUs x ~3 blocks; big layers need no split
     const int64_t max_split = (N + 255) / 256;           // at least 256 reduction elements per block
     if (want > max_split) want = max_split;
     if (want > 512) want = 512;
@@ -753,24 +785,43 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk) {
     ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
     *chunk = (int)ch;
     *nsplit = (int)((N + ch - 1) / ch);
+    if (tiles_out) *tiles_out = (int)tiles;
+}
+
+static int wgrad_reduce_grid(int64_t n) {
+    int g = stream_grid(n, 1024);
+    return g > 512 ? 512 : g;
 }
 
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
     const ConvGeom g = make_geom(geom);
-    int bm, nsplit, chunk;
-    wgrad_plan(g, &bm, &nsplit, &chunk);
-    return (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float);
+    int bm, nsplit, chunk, tiles;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
+    return nsplit > 1 ? (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float) : 0;
 }
 
-// gw: [M, C, KH, KW], overwritten.
+// number of doubles written to `inner_partial` by locate_conv_wgrad for this geometry
+LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
+    const ConvGeom g = make_geom(geom);
+    int bm, nsplit, chunk, tiles;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
+    return nsplit > 1 ? wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW) : tiles;
+}
+
+// gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw]          (overwritten)
+// With w_ref (= W_bar, same layout as gw) and inner_partial: the partial sums of <UNSCALED gw, W_bar> the
+// spectral-norm backward needs come out of the same pass (locate_conv_wgrad_partials(geom) doubles).
 LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
-                                 void* workspace, void* stream) {
+                                 const float* w_ref, const float* inv_scale, double* inner_partial, void* workspace,
+                                 void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
-    LOCATE_REQUIRE(workspace && x && gy && gw, "locate_conv_wgrad: null pointer");
+    LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
+    LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
     hipStream_t st = as_stream(stream);
-    int bm, nsplit, chunk;
-    wgrad_plan(g, &bm, &nsplit, &chunk);
+    int bm, nsplit, chunk, tiles;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
+    LOCATE_REQUIRE(nsplit == 1 || workspace, "locate_conv_wgrad: split reduction needs a workspace");
     WgParams p;
     p.x = x; p.gy = gy; p.slab = static_cast<float*>(workspace); p.x_bs = x_bs; p.gy_bs = gy_bs;
     p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW; p.KH = g.KH; p.KW = g.KW;
@@ -778,14 +829,21 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     p.R = g.C * g.KH * g.KW; p.N = g.B * g.OH * g.OW; p.chunk = chunk;
     fastdiv_make((unsigned)(g.OH * g.OW), &p.q_mul, &p.q_s1, &p.q_s2);
     fastdiv_make((unsigned)g.OW, &p.ow_mul, &p.ow_s1, &p.ow_s2);
+    const bool direct = nsplit == 1;
+    p.direct_out = direct ? gw : nullptr;
+    p.w_ref = direct ? w_ref : nullptr;
+    p.inv_scale = direct ? inv_scale : nullptr;
+    p.partial = direct ? inner_partial : nullptr;
     dim3 grid((p.R + 127) / 128, (g.M + bm - 1) / bm, nsplit);
     if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
     else if (bm == 96) conv_wgrad_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
     else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
     else conv_wgrad_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     LOCATE_LAUNCH_CHECK("locate_conv_wgrad(gemm)");
-    const int64_t n = (int64_t)g.M * p.R;
-    slab_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>(p.slab, gw, n, nsplit);
-    LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
+    if (!direct) {
+        const int64_t n = (int64_t)g.M * p.R;
+        slab_reduce_kernel<<<wgrad_reduce_grid(n), 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
+        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
+    }
     return LOCATE_OK;
 }

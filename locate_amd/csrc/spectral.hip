@@ -169,22 +169,13 @@ LOCATE_API int locate_sn_power_iter_batched(const void* table, int n_layers, int
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sn_inner_kernel(const float* __restrict__ g, const float* __restrict__ w, int64_t n,
-                                                       double* __restrict__ partial) {
-    __shared__ double scratch[16];
-    double acc = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (double)g[i] * (double)w[i];
-    acc = block_sum<double>(acc, scratch);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-}
-
-// dw = g / sigma + dsigma * u v^T ; block 0 also writes du = dsigma * wv and consts[0] = dsigma
-__global__ void __launch_bounds__(256) sn_dw_kernel(const float* __restrict__ g, const float* __restrict__ u,
-                                                    const float* __restrict__ v, const float* __restrict__ sigma,
-                                                    const float* __restrict__ wv, const double* __restrict__ partial,
-                                                    int npartial, float* __restrict__ dw, float* __restrict__ du,
-                                                    float* __restrict__ dsigma_out, int h, int wd) {
+// gw holds G / sigma (written by the weight-gradient pass, which also left the partial sums of <G, W_bar>):
+//   dsigma = -(sum partial) / sigma^2 ;  gw += dsigma * u v^T ;  block 0: du = dsigma * wv, dsigma_out = dsigma
+__global__ void __launch_bounds__(256) sn_rank1_kernel(const double* __restrict__ partial, int npartial,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ sigma, const float* __restrict__ wv,
+                                                       float* __restrict__ gw, float* __restrict__ du,
+                                                       float* __restrict__ dsigma_out, int h, int wd) {
     __shared__ double scratch[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
@@ -195,7 +186,7 @@ __global__ void __launch_bounds__(256) sn_dw_kernel(const float* __restrict__ g,
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
-        dw[i] = g[i] / sg + dsg * u[r] * v[c];
+        gw[i] = fmaf(dsg * u[r], v[c], gw[i]);
     }
     if (blockIdx.x == 0) {
         if (du)
@@ -210,28 +201,25 @@ __global__ void __launch_bounds__(SN_COLS) sn_dv_kernel(const float* __restrict_
     if (col < wd) dv[col] = dsigma[0] * t[col];
 }
 
-LOCATE_API size_t locate_sn_bwd_workspace_bytes(int h, int wd) {
-    return 512 * sizeof(double) + 16 + locate_sn_workspace_bytes(h, wd);
-}
+LOCATE_API size_t locate_sn_bwd_workspace_bytes(int h, int wd) { return 16 + locate_sn_workspace_bytes(h, wd); }
 
-// g: gradient w.r.t. the normalised weight W_bar/sigma (same layout as W_bar).  sigma: the [2] buffer of the
-// forward being differentiated; wv: that forward's W v; u, v: CURRENT (latest) state.  du / dv may be null.
-LOCATE_API int locate_sn_weight_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma,
-                                    const float* wv, float* dw, float* du, float* dv, int h, int wd, void* workspace,
-                                    void* stream) {
-    LOCATE_REQUIRE(h > 0 && wd > 0 && g && w && u && v && sigma && dw && workspace, "locate_sn_weight_bwd: bad arguments");
+// Spectral-norm backward after locate_conv_wgrad(..., w_ref = W_bar, inv_scale = 1/sigma, inner_partial):
+//   gw (in/out) enters as G / sigma and leaves as dW_bar = G / sigma + dsigma u v^T,  dsigma = -<G, W_bar> / sigma^2,
+//   du = dsigma (W v)_k, dv = dsigma W^T u (du, dv nullable; w only needed for dv).  sigma: the [2] buffer and wv the
+//   W v of the forward being differentiated; u, v: CURRENT (latest) state, as the reference's autograd sees them.
+LOCATE_API int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* w, const float* u, const float* v,
+                                    const float* sigma, const float* wv, float* gw, float* du, float* dv, int h, int wd,
+                                    void* workspace, void* stream) {
+    LOCATE_REQUIRE(h > 0 && wd > 0 && inner_partial && n_partial > 0 && u && v && sigma && gw && workspace,
+                   "locate_sn_weight_bwd: bad arguments");
     LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd: du requested without the saved W v");
+    LOCATE_REQUIRE(!dv || w, "locate_sn_weight_bwd: dv requested without W_bar");
     hipStream_t st = as_stream(stream);
-    double* partial = static_cast<double*>(workspace);
-    float* dsig = reinterpret_cast<float*>(partial + 512);
+    float* dsig = static_cast<float*>(workspace);
     float* ws = dsig + 4;
     const int64_t n = (int64_t)h * wd;
-    int nb = stream_grid(n, 1024);
-    if (nb > 512) nb = 512;
-    sn_inner_kernel<<<nb, 256, 0, st>>>(g, w, n, partial);
-    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(inner)");
-    sn_dw_kernel<<<stream_grid(n, 1024), 256, 0, st>>>(g, u, v, sigma, wv, partial, nb, dw, du, dsig, h, wd);
-    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(dw)");
+    sn_rank1_kernel<<<stream_grid(n, 1024), 256, 0, st>>>(inner_partial, n_partial, u, v, sigma, wv, gw, du, dsig, h, wd);
+    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(rank1)");
     if (dv) {
         // dv = dsigma * W^T u (latest u): reuse the column-sum kernels
         const SnLayer L = sn_make(w, const_cast<float*>(u), nullptr, nullptr, nullptr, h, wd, ws);

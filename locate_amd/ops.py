@@ -461,21 +461,23 @@ class SNConvFn(torch.autograd.Function):
                 check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 0)), _p(inv_sigma), None, _p(gx),
                                         _bs(gx), _p(ws), st), "locate_conv_fwd")
         if need_w or need_u or need_v:
-            g_wn = torch.empty_like(w)     # gradient w.r.t. the normalised weight W_bar / sigma
+            # one pass: gw = G / sigma_k (G = gradient w.r.t. the normalised weight) plus the partial sums of <G, W_bar>;
+            # then the rank-1 spectral-norm correction in place
+            gw = torch.empty_like(w)
+            npart = L.locate_conv_wgrad_partials(garr)
+            partial = torch.empty(npart, dtype=torch.float64, device=x.device)
             ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
-            if spec.kind == "conv":
-                check(L.locate_conv_wgrad(garr, _p(x), _bs(x), _p(gy), _bs(gy), _p(g_wn), _p(ws), st), "locate_conv_wgrad")
-            else:   # roles swapped: R's input is gy, R's output-gradient is x
-                check(L.locate_conv_wgrad(garr, _p(gy), _bs(gy), _p(x), _bs(x), _p(g_wn), _p(ws), st), "locate_conv_wgrad")
+            xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
+            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), _p(partial),
+                                      _p(ws), st), "locate_conv_wgrad")
             h = w.shape[0]
             wd = w.numel() // h
-            gw = torch.empty_like(w)
             u, v = ctx.u.detach(), ctx.v.detach()
             gu = torch.empty_like(u) if need_u else None
             gv = torch.empty_like(v) if need_v else None
             ws2 = _ws(L.locate_sn_bwd_workspace_bytes(h, wd), x.device)
-            check(L.locate_sn_weight_bwd(_p(g_wn), _p(w), _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(gv), h, wd, _p(ws2),
-                                         st), "locate_sn_weight_bwd")
+            check(L.locate_sn_weight_bwd(_p(partial), npart, _p(w), _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(gv), h, wd,
+                                         _p(ws2), st), "locate_sn_weight_bwd")
             if not need_w:
                 gw = None
         if ctx.has_bias and need_b:

@@ -74,6 +74,7 @@ def main():
         check(L.locate_conv_pack_panel(garr, 1, w.data_ptr(), pan1.data_ptr(), st))
         ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
         ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+        part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
         ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
 
         def r_fwd(inp, out):      # R forward
@@ -87,11 +88,11 @@ def main():
         if kind == "conv":
             fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
-                                                    ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), part.data_ptr(), ws_w.data_ptr(), st))
         else:
             fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
-                                                    ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), part.data_ptr(), ws_w.data_ptr(), st))
         OH = out_shape[2]
         if kind == "conv":
             flops = 2.0 * B * OH * OH * cout * cin * k * k
