@@ -751,19 +751,38 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     }
 }
 
-// out = (sum_z slab[z]) * inv_scale;  partial[block] = this block's share of <sum_z slab[z], w_ref>
+// out = (sum_z slab[z]) * inv_scale;  partial[block] = this block's share of <sum_z slab[z], w_ref>.
+// ZP = 1: one thread per element walks all slabs.  ZP = 4: four z-groups per element (many slabs, few elements: the
+// 1x1 / attention layers), combined through LDS in a fixed order - results stay bit-reproducible.
+template <int ZP>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
                                                           int nsplit, const float* __restrict__ w_ref,
                                                           const float* __restrict__ inv_scale, double* __restrict__ partial) {
     __shared__ double scratch[16];
+    __shared__ float zsum[ZP][256 / ZP];
     const float sc = inv_scale ? inv_scale[0] : 1.0f;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    constexpr int EPB = 256 / ZP;                       // elements per block pass
+    const int ex = threadIdx.x % EPB, ez = threadIdx.x / EPB;
+    const int64_t stride = (int64_t)gridDim.x * EPB;
     double dot = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < n; i0 += stride) {
+        const int64_t i = i0 + ex;
         float acc = 0.0f;
-        for (int z = 0; z < nsplit; ++z) acc += slab[(int64_t)z * n + i];
-        if (w_ref) dot += (double)acc * (double)w_ref[i];
-        out[i] = acc * sc;
+        if (i < n)
+            for (int z = ez; z < nsplit; z += ZP) acc += slab[(int64_t)z * n + i];
+        if (ZP > 1) {
+            __syncthreads();
+            zsum[ez][ex] = acc;
+            __syncthreads();
+            acc = 0.0f;
+            if (ez == 0)
+#pragma unroll
+                for (int g = 0; g < ZP; ++g) acc += zsum[g][ex];
+        }
+        if (ez == 0 && i < n) {
+            if (w_ref) dot += (double)acc * (double)w_ref[i];
+            out[i] = acc * sc;
+        }
     }
     if (partial) {
         dot = block_sum<double>(dot, scratch);
@@ -776,7 +795,7 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     const int R = g.C * g.KH * g.KW;
     const int64_t N = (int64_t)g.B * g.OH * g.OW;
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
-    int64_t want = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;      // fill 256 CUs x ~3 blocks; big layers need no split
+    int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks (256 CUs x 2 resident x 2 rounds)
     const int64_t max_split = (N + 255) / 256;           // at least 256 reduction elements per block
     if (want > max_split) want = max_split;
     if (want > 512) want = 512;
@@ -788,8 +807,10 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     if (tiles_out) *tiles_out = (int)tiles;
 }
 
-static int wgrad_reduce_grid(int64_t n) {
-    int g = stream_grid(n, 1024);
+static int wgrad_reduce_zp(int nsplit, int64_t n) { return (nsplit >= 16 && n < (1 << 20)) ? 4 : 1; }
+static int wgrad_reduce_grid(int64_t n, int nsplit) {
+    const int epb = 256 / wgrad_reduce_zp(nsplit, n);
+    int g = stream_grid(n, epb);
     return g > 512 ? 512 : g;
 }
 
@@ -805,7 +826,7 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
     const ConvGeom g = make_geom(geom);
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
-    return nsplit > 1 ? wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW) : tiles;
+    return nsplit > 1 ? wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW, nsplit) : tiles;
 }
 
 // gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw]          (overwritten)
@@ -842,7 +863,11 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     LOCATE_LAUNCH_CHECK("locate_conv_wgrad(gemm)");
     if (!direct) {
         const int64_t n = (int64_t)g.M * p.R;
-        slab_reduce_kernel<<<wgrad_reduce_grid(n), 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
+        const int rg = wgrad_reduce_grid(n, nsplit);
+        if (wgrad_reduce_zp(nsplit, n) == 4)
+            slab_reduce_kernel<4><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
+        else
+            slab_reduce_kernel<1><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
     }
     return LOCATE_OK;
