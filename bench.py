@@ -128,7 +128,8 @@ def main():
     if world > 1:
         broadcast_module_state(G, 0, extra_tensors=[G.noise])
         broadcast_module_state(D, 0)
-        red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters())
+        late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
+        red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters(), late=late_v)
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)

@@ -83,12 +83,13 @@ int locate_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
 size_t locate_sn_table_record_bytes(void);
 int locate_sn_power_iter_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream);
 /* after locate_conv_wgrad(.., w_ref = W_bar, inv_scale = 1/sigma, inner_partial): gw (in/out) enters as G/sigma and
- * leaves as dW_bar = G/sigma + dsigma u v^T; du = dsigma (W v), dv = dsigma W^T u with dsigma = -<G, W_bar>/sigma^2;
- * u, v are the CURRENT state (the reference's autograd sees the latest .data); du, dv nullable; w only needed for dv */
-size_t locate_sn_bwd_workspace_bytes(int h, int wd);
-int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* w, const float* u, const float* v,
-                         const float* sigma, const float* wv, float* gw, float* du, float* dv, int h, int wd,
-                         void* workspace, void* stream);
+ * leaves as dW_bar = G/sigma + dsigma u v^T with dsigma = -<G, W_bar>/sigma^2; du = dsigma (W v) (nullable);
+ * dsigma_out[0] = dsigma (nullable).  u, v are the CURRENT state (the reference's autograd sees the latest .data). */
+int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* u, const float* v, const float* sigma,
+                         const float* wv, float* gw, float* du, float* dsigma_out, int h, int wd, void* stream);
+/* dv = (sum of the layer's 4 dsigma slots) * W^T u for all layers of `table` (records as for
+ * locate_sn_power_iter_batched; field v = dv output, field sigma = the 4 slots, cleared afterwards) */
+int locate_sn_dv_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream);
 
 /* ---- dense contractions as implicit GEMMs on the fp32 MFMA (libs/conv.py:14-20, libs/attention.py:18-46,
  *      libs/scale.py:25-34, libs/linear.py:10).  geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW}

@@ -50,8 +50,8 @@ PROTOTYPES = {
     "locate_sn_power_iter": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "locate_sn_table_record_bytes": (c_sz, []),
     "locate_sn_power_iter_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
-    "locate_sn_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
-    "locate_sn_weight_bwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "locate_sn_weight_bwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "locate_sn_dv_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_conv_panel_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),

@@ -191,45 +191,57 @@ __global__ void __launch_bounds__(256) sn_rank1_kernel(const double* __restrict_
     if (blockIdx.x == 0) {
         if (du)
             for (int i = threadIdx.x; i < h; i += blockDim.x) du[i] = dsg * wv[i];
-        if (threadIdx.x == 0) dsigma_out[0] = dsg;
+        if (threadIdx.x == 0 && dsigma_out) dsigma_out[0] = dsg;
     }
 }
 
-__global__ void __launch_bounds__(SN_COLS) sn_dv_kernel(const float* __restrict__ t, const float* __restrict__ dsigma,
-                                                        float* __restrict__ dv, int wd) {
+// dv[col] = (sum of the layer's dsigma slots) * t[col];  the slots are cleared for the next backward pass
+__global__ void __launch_bounds__(SN_COLS) sn_dv_batched_kernel(const SnLayer* __restrict__ table) {
+    const SnLayer L = table[blockIdx.y];
     const int col = blockIdx.x * SN_COLS + threadIdx.x;
-    if (col < wd) dv[col] = dsigma[0] * t[col];
+    // record reuse: L.v = dv output, L.sigma = dsigma slots [4]
+    const float total = (L.sigma[0] + L.sigma[1]) + (L.sigma[2] + L.sigma[3]);
+    if (col < L.wd) L.v[col] = total * L.t[col];
 }
 
-LOCATE_API size_t locate_sn_bwd_workspace_bytes(int h, int wd) { return 16 + locate_sn_workspace_bytes(h, wd); }
+__global__ void __launch_bounds__(64) sn_dsig_clear_kernel(const SnLayer* __restrict__ table, int n_layers) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_layers * 4) table[i >> 2].sigma[i & 3] = 0.0f;
+}
 
 // Spectral-norm backward after locate_conv_wgrad(..., w_ref = W_bar, inv_scale = 1/sigma, inner_partial):
 //   gw (in/out) enters as G / sigma and leaves as dW_bar = G / sigma + dsigma u v^T,  dsigma = -<G, W_bar> / sigma^2,
-//   du = dsigma (W v)_k, dv = dsigma W^T u (du, dv nullable; w only needed for dv).  sigma: the [2] buffer and wv the
-//   W v of the forward being differentiated; u, v: CURRENT (latest) state, as the reference's autograd sees them.
-LOCATE_API int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* w, const float* u, const float* v,
-                                    const float* sigma, const float* wv, float* gw, float* du, float* dv, int h, int wd,
-                                    void* workspace, void* stream) {
-    LOCATE_REQUIRE(h > 0 && wd > 0 && inner_partial && n_partial > 0 && u && v && sigma && gw && workspace,
-                   "locate_sn_weight_bwd: bad arguments");
+//   du = dsigma (W v)_k (nullable), dsigma_out[0] = dsigma (nullable; feeds locate_sn_dv_batched).
+//   sigma: the [2] buffer and wv the W v of the forward being differentiated; u, v: CURRENT (latest) state, as the
+//   reference's autograd sees them.
+LOCATE_API int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* u, const float* v,
+                                    const float* sigma, const float* wv, float* gw, float* du, float* dsigma_out, int h,
+                                    int wd, void* stream) {
+    LOCATE_REQUIRE(h > 0 && wd > 0 && inner_partial && n_partial > 0 && u && v && sigma && gw, "locate_sn_weight_bwd: bad arguments");
     LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd: du requested without the saved W v");
-    LOCATE_REQUIRE(!dv || w, "locate_sn_weight_bwd: dv requested without W_bar");
-    hipStream_t st = as_stream(stream);
-    float* dsig = static_cast<float*>(workspace);
-    float* ws = dsig + 4;
     const int64_t n = (int64_t)h * wd;
-    sn_rank1_kernel<<<stream_grid(n, 1024), 256, 0, st>>>(inner_partial, n_partial, u, v, sigma, wv, gw, du, dsig, h, wd);
+    sn_rank1_kernel<<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(inner_partial, n_partial, u, v, sigma, wv, gw, du,
+                                                                         dsigma_out, h, wd);
     LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(rank1)");
-    if (dv) {
-        // dv = dsigma * W^T u (latest u): reuse the column-sum kernels
-        const SnLayer L = sn_make(w, const_cast<float*>(u), nullptr, nullptr, nullptr, h, wd, ws);
-        const int nstrip = (wd + SN_COLS - 1) / SN_COLS;
-        sn_colsum_kernel<false><<<nstrip * L.nchunk, SN_COLS, 0, st>>>(L, nullptr);
-        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(colsum)");
-        sn_tsum_kernel<false><<<nstrip, SN_COLS, 0, st>>>(L, nullptr);
-        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(tsum)");
-        sn_dv_kernel<<<nstrip, SN_COLS, 0, st>>>(L.t, dsig, dv, wd);
-        LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd(dv)");
-    }
+    return LOCATE_OK;
+}
+
+// dv = (sum_k dsigma_k) * W^T u_latest for every layer of `table` in three launches (same record layout as
+// locate_sn_power_iter_batched with two fields reused: v = dv output [wd], sigma = the layer's 4 dsigma slots, which
+// are zeroed afterwards).  Called once at the end of a backward pass instead of three launches per layer and graph.
+LOCATE_API int locate_sn_dv_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream) {
+    LOCATE_REQUIRE(table && n_layers > 0 && max_h > 0 && max_wd > 0, "locate_sn_dv_batched: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const SnLayer* tab = static_cast<const SnLayer*>(table);
+    SnLayer dummy = {};
+    const int nstrip = (max_wd + SN_COLS - 1) / SN_COLS;
+    sn_colsum_kernel<true><<<dim3(nstrip * sn_nchunk(max_h), n_layers), SN_COLS, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_dv_batched(colsum)");
+    sn_tsum_kernel<true><<<dim3(nstrip, n_layers), SN_COLS, 0, st>>>(dummy, tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_dv_batched(tsum)");
+    sn_dv_batched_kernel<<<dim3(nstrip, n_layers), SN_COLS, 0, st>>>(tab);
+    LOCATE_LAUNCH_CHECK("locate_sn_dv_batched(dv)");
+    sn_dsig_clear_kernel<<<(n_layers * 4 + 63) / 64, 64, 0, st>>>(tab, n_layers);
+    LOCATE_LAUNCH_CHECK("locate_sn_dv_batched(clear)");
     return LOCATE_OK;
 }

@@ -388,6 +388,68 @@ def _panel(owner, w, geom, garr, adjoint):
     return buf
 
 
+# ------------------------------------------------------------------------------------------------
+# gradient of the spectral-norm v vectors, batched per backward pass
+#   dv = (sum_k dsigma_k) * W^T u_latest  - the same W^T u for every graph that used the layer, so it is computed
+#   once per layer and pass, for all layers in three launches, from a callback at the end of the backward pass
+#   (instead of three launches per layer and graph).  The result is written to a persistent buffer that becomes
+#   v.grad (accumulated into an existing foreign .grad).
+# ------------------------------------------------------------------------------------------------
+class _PendingDV:
+    layers = {}          # id(v) -> (v, u, w, h, wd, state)
+    scheduled = False
+    tables = {}          # tuple(ids) -> (device table, max_h, max_wd, keep-alive)
+
+
+def _register_pending_dv(v_param, u_param, w, h, wd):
+    st = v_param.__dict__.get("_locate_dv")
+    if st is None or st["dv"].device != v_param.device:
+        nch = (h + 63) // 64
+        st = {"dv": torch.empty_like(v_param.detach()), "dsig": torch.zeros(4, dtype=torch.float32, device=v_param.device),
+              "scratch": torch.empty(wd + h + nch * wd, dtype=torch.float32, device=v_param.device), "k": 0}
+        v_param.__dict__["_locate_dv"] = st
+    k = st["k"]
+    if k >= 4:
+        raise RuntimeError("a spectral-norm layer was differentiated through more than 4 forwards in one backward pass")
+    st["k"] = k + 1
+    _PendingDV.layers[id(v_param)] = (v_param, u_param, w, h, wd, st)
+    if not _PendingDV.scheduled:
+        torch.autograd.Variable._execution_engine.queue_callback(_finalize_pending_dv)
+        _PendingDV.scheduled = True
+    return st["dsig"][k:]
+
+
+def _finalize_pending_dv():
+    import struct
+    layers = list(_PendingDV.layers.values())
+    _PendingDV.layers = {}
+    _PendingDV.scheduled = False
+    if not layers:
+        return
+    key = tuple((id(v), w.data_ptr(), u.data_ptr()) for v, u, w, _, _, _ in layers)
+    tab = _PendingDV.tables.get(key)
+    if tab is None:
+        rec = struct.Struct("<8Q4i")
+        buf = bytearray()
+        for v, u, w, h, wd, st in layers:
+            base = st["scratch"].data_ptr()
+            buf += rec.pack(w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["dsig"].data_ptr(), 0, base, base + 4 * wd,
+                            base + 4 * (wd + h), h, wd, (h + 63) // 64, 0)
+        host = torch.frombuffer(buf, dtype=torch.uint8).clone()
+        dev_tab = host.to(layers[0][0].device)
+        tab = (dev_tab, max(l[3] for l in layers), max(l[4] for l in layers), [l[2] for l in layers])
+        if len(_PendingDV.tables) > 8:
+            _PendingDV.tables.clear()
+        _PendingDV.tables[key] = tab
+    check(lib().locate_sn_dv_batched(tab[0].data_ptr(), len(layers), tab[1], tab[2], _stream()), "locate_sn_dv_batched")
+    for v, u, w, h, wd, st in layers:
+        st["k"] = 0
+        if v.grad is None or v.grad is st["dv"]:
+            v.grad = st["dv"]
+        else:
+            v.grad.add_(st["dv"])
+
+
 def sn_power_iteration(w_bar, u, v):
     """One power iteration on (u, v) IN PLACE (untracked, like the reference's `.data` writes,
     libs/spectral_norm.py:26-29).  Returns (sigma[2] = {sigma, 1/sigma}, wv[h] = W v)."""
@@ -474,10 +536,10 @@ class SNConvFn(torch.autograd.Function):
             wd = w.numel() // h
             u, v = ctx.u.detach(), ctx.v.detach()
             gu = torch.empty_like(u) if need_u else None
-            gv = torch.empty_like(v) if need_v else None
-            ws2 = _ws(L.locate_sn_bwd_workspace_bytes(h, wd), x.device)
-            check(L.locate_sn_weight_bwd(_p(partial), npart, _p(w), _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(gv), h, wd,
-                                         _p(ws2), st), "locate_sn_weight_bwd")
+            dsig = _register_pending_dv(ctx.v, ctx.u, w, h, wd) if need_v else None
+            check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
+                  "locate_sn_weight_bwd")
+            gv = None      # assigned to v.grad by _finalize_pending_dv at the end of this backward pass
             if not need_w:
                 gw = None
         if ctx.has_bias and need_b:

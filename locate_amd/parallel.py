@@ -27,8 +27,19 @@ def broadcast_module_state(module, src=0, extra_tensors=()):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None):
+        """`late`: predicate (or collection) of parameters whose .grad is only assigned at the very end of the backward
+        pass, outside autograd's accumulation (the spectral-norm v vectors, ops._finalize_pending_dv).  They get buckets
+        of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients."""
         self.params = [p for p in params]
+        if late is None:
+            is_late = [False] * len(self.params)
+        elif callable(late):
+            is_late = [bool(late(p)) for p in self.params]
+        else:
+            late_ids = {id(p) for p in late}
+            is_late = [id(p) in late_ids for p in self.params]
+        self.is_late = is_late
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
@@ -36,16 +47,20 @@ class GradAllReducer:
         # reverse order ~ gradient production order
         self.buckets = []          # list of lists of parameter indices
         cur, cur_bytes = [], 0
-        for idx in reversed(range(len(self.params))):
-            p = self.params[idx]
-            nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
+        for group_late in (False, True):
+            cur, cur_bytes = [], 0
+            for idx in reversed(range(len(self.params))):
+                if is_late[idx] != group_late:
+                    continue
+                p = self.params[idx]
+                nbytes = p.numel() * p.element_size()
+                if cur and cur_bytes + nbytes > bucket_bytes:
+                    self.buckets.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(idx)
+                cur_bytes += nbytes
+            if cur:
                 self.buckets.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(idx)
-            cur_bytes += nbytes
-        if cur:
-            self.buckets.append(cur)
         self.bucket_of = {}
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
@@ -73,7 +88,7 @@ class GradAllReducer:
         # hooks are (re)registered lazily: a tensor can only carry one once it requires grad, and the
         # discriminator's u/v only start to after the first G-step (reference main.py:172)
         for i, p in enumerate(self.params):
-            if p.requires_grad and i not in self._hooked:
+            if p.requires_grad and i not in self._hooked and not self.is_late[i]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
                 self._hooked.add(i)
         self._ready = [0] * len(self.buckets)
@@ -81,7 +96,8 @@ class GradAllReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._active = True
-        self._expected = [sum(1 for i in idxs if self.params[i].requires_grad) for idxs in self.buckets]
+        self._expected = [sum(1 for i in idxs if self.params[i].requires_grad and not self.is_late[i]) or -1
+                          for idxs in self.buckets]     # -1: a late-only bucket is never launched from a hook
 
     def _make_hook(self, i):
         def hook(p):

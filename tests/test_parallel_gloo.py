@@ -30,8 +30,10 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
         frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)   # like D's u/v before main.py:172
         extra = torch.randn(1, 3, 2, 2)                      # like Generator.noise
         broadcast_module_state(net, 0, extra_tensors=[extra, unused.data, frozen.data])
-        params = list(net.parameters()) + [unused, frozen]
-        red = GradAllReducer(params, bucket_bytes=bucket_bytes, overlap=overlap)
+        late = torch.nn.Parameter(torch.randn(3))              # like D's spectral-norm v: .grad assigned after backward
+        broadcast_module_state(torch.nn.ParameterList([late]), 0)
+        params = list(net.parameters()) + [unused, frozen, late]
+        red = GradAllReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, late=[late])
         torch.manual_seed(7)                                  # same data stream on both ranks, shard by rank
         x = torch.randn(8, 6)
         shard = x[rank * 4:(rank + 1) * 4]
@@ -42,6 +44,7 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
             loss = net(shard).pow(2).mean() * (it + 1)
             red.begin()
             loss.backward()
+            late.grad = torch.full((3,), float(rank + 1 + it))   # assigned outside autograd, before finish()
             red.finish()
             results.append([None if p.grad is None else p.grad.clone() for p in params])
         # single-process truth: mean over the two shards' gradients
@@ -52,6 +55,7 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
                 for p in params:
                     p.grad = None
                 (net(x[r * 4:(r + 1) * 4]).pow(2).mean() * (it + 1)).backward()
+                late.grad = torch.full((3,), float(r + 1 + it))
                 g = [None if p.grad is None else p.grad.clone() for p in params]
                 acc = g if acc is None else [None if a is None else a + b for a, b in zip(acc, g)]
             truth.append([None if a is None else a / world for a in acc])
