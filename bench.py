@@ -137,7 +137,7 @@ def main():
     real = torch.randn(B, 3, S, S, generator=gen).clamp(-1, 1).to(dev)
     aug = torch.randn(B, 3, S, S, generator=gen).clamp(-1, 1).to(dev)
 
-    use_graph = not args.no_graph and world == 1
+    use_graph = not args.no_graph
     runner = GraphedTrainStep(step, latent, real, aug, warmup=2) if use_graph else None
 
     def one_step():
@@ -176,7 +176,8 @@ def main():
             "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (BASELINE.json configs[1]), "
                                    "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": ("hipGraph replay" + (" + eager RCCL all-reduce between graphs" if world > 1 else ""))
+                                 if use_graph else "eager (all-reduce overlapped with backward)"},
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }
         line["roofline"] = conv_roofline(cfg, B, dev)

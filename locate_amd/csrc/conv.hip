@@ -74,7 +74,12 @@ struct PackArgs {
 
 static inline size_t panel_floats(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
 
-__global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
+struct PackBatch {
+    PackArgs ph[4];
+};
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackBatch batch) {
+    const PackArgs& a = batch.ph[blockIdx.y];
     const int64_t total = (int64_t)a.rows * a.ld;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int T = a.TH * a.TW;
@@ -401,8 +406,14 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     return LOCATE_OK;
 }
 
-static int launch_pack(const PackArgs& a, hipStream_t st, const char* who) {
-    pack_weights_kernel<<<stream_grid((int64_t)a.rows * a.ld, 256), 256, 0, st>>>(a);
+// all phases of one panel in a single launch (blockIdx.y = phase)
+static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const char* who) {
+    int64_t big = 1;
+    for (int i = 0; i < nphase; ++i) {
+        const int64_t t = (int64_t)b.ph[i].rows * b.ph[i].ld;
+        if (t > big) big = t;
+    }
+    pack_weights_kernel<<<dim3(stream_grid(big, 256), nphase), 256, 0, st>>>(b);
     LOCATE_LAUNCH_CHECK(who);
     return LOCATE_OK;
 }
@@ -449,6 +460,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
     size_t off = 0;
     int nmax = 0;
     p.nphase = 0;
+    PackBatch batch;
     if (!adjoint) {
         p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW;
         p.istride = g.stride; p.ostep = 1; p.nphase = 1;
@@ -458,8 +470,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
         pa.K = g.C * g.KH * g.KW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
         pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = -g.pad_h; pa.dys = 1; pa.dx0 = -g.pad_w; pa.dxs = 1;
-        if (pack)
-            if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
+        batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
         ph.T = g.KH * g.KW;
@@ -484,8 +495,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
                 pa.K = g.M * TH * TW; pa.rows = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.C, 32);
                 pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
-                if (pack)
-                    if (int e = launch_pack(pa, st, "locate_conv_pack_panel")) return e;
+                batch.ph[p.nphase - 1] = pa;
                 phase_finish(ph, pa, pa.out);
                 ph.T = TH * TW;
                 ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
@@ -496,6 +506,8 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
     }
     if (nmax_out) *nmax_out = nmax;
     if (panel_floats_out) *panel_floats_out = off;
+    if (pack && p.nphase > 0)
+        if (int e = launch_pack(batch, p.nphase, st, "locate_conv_pack_panel")) return e;
     return LOCATE_OK;
 }
 
@@ -726,22 +738,33 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     float* dst = direct ? p.direct_out : p.slab + (long long)blockIdx.z * p.M * p.R;
     const float sc = (direct && p.inv_scale) ? p.inv_scale[0] : 1.0f;
     double dot = 0.0;
+    const bool want_dot = direct && p.w_ref != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + lcol;
-        if (r >= p.R) continue;
+        const bool r_ok = r < p.R;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            // this lane's 16 rows of the 32x32 tile: W_bar values first (branch-free, all loads in flight), then the
+            // products in fp32 per tile and the running sum in fp64
+            float wref[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
-                if (m < p.M) {
-                    const long long idx = (long long)m * p.R + r;
-                    const float v = acc[i][j][e];
-                    if (direct && p.w_ref) dot += (double)v * (double)p.w_ref[idx];
-                    dst[idx] = v * sc;
-                }
+                const bool ok = want_dot && r_ok && m < p.M;
+                const float* wp_ = ok ? p.w_ref + (long long)m * p.R + r : p.gy;      // always a mapped address
+                wref[e] = ok ? *wp_ : 0.0f;
             }
+            float part = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
+                const float v = acc[i][j][e];
+                part = fmaf(v, wref[e], part);
+                if (r_ok && m < p.M) dst[(long long)m * p.R + r] = v * sc;
+            }
+            dot += (double)part;
+        }
     }
     if (direct && p.partial) {
         dot = wave_sum_d(dot);

@@ -39,12 +39,19 @@ class GraphedTrainStep:
             if out:
                 self.outputs.update(out)
 
-        capture(lambda: step.d_forward_backward(lat, real_, aug_))
-        self._prime(step.dis_opt)
-        capture(step.d_optimizer)
-        capture(lambda: step.g_forward_backward(lat))
-        self._prime(step.gen_opt)
-        capture(step.g_optimizer)
+        # data parallel: the collectives stay OUTSIDE the graphs (replay: backward graph -> eager bucketed all-reduce ->
+        # optimizer graph), so nothing RCCL-related is ever captured
+        self.reducers = (step.reducer_d, step.reducer_g)
+        step.reducer_d = step.reducer_g = None
+        try:
+            capture(lambda: step.d_forward_backward(lat, real_, aug_))
+            self._prime(step.dis_opt)
+            capture(step.d_optimizer)
+            capture(lambda: step.g_forward_backward(lat))
+            self._prime(step.gen_opt)
+            capture(step.g_optimizer)
+        finally:
+            step.reducer_d, step.reducer_g = self.reducers
 
     @staticmethod
     def _prime(opt):
@@ -59,8 +66,15 @@ class GraphedTrainStep:
         for dst, src in zip(self.inputs, (latent, real, aug)):
             if src is not None:
                 dst.copy_(src)
-        for g in self.graphs:
-            g.replay()
+        red_d, red_g = self.reducers
+        self.graphs[0].replay()
+        if red_d is not None:
+            red_d.reduce_now()
+        self.graphs[1].replay()
+        self.graphs[2].replay()
+        if red_g is not None:
+            red_g.reduce_now()
+        self.graphs[3].replay()
         # the replayed optimizer kernels changed the weights behind Python's back: bump the version counters so
         # that any later EAGER use (sampling, evaluation) re-packs its weight panels instead of trusting the cache
         torch._C._increment_version(self._params)

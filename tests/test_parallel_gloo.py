@@ -66,6 +66,16 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
                     ok = False
                 elif a is not None and not torch.allclose(a, b, rtol=1e-6, atol=1e-7):
                     ok = False
+        # non-overlapped form used between captured graphs
+        for p in params:
+            p.grad = None
+        (net(shard).pow(2).mean()).backward()
+        late.grad = torch.full((3,), float(rank + 1))
+        red.reduce_now()
+        now = [None if p.grad is None else p.grad.clone() for p in params]
+        for a, b in zip(now, truth[0]):
+            if (a is None) != (b is None) or (a is not None and not torch.allclose(a, b, rtol=1e-6, atol=1e-7)):
+                ok = False
         w0 = [p.detach().clone() for p in net.parameters()] + [extra]
         gathered = [None] * world
         dist.all_gather_object(gathered, [t.tolist() for t in w0])
