@@ -90,6 +90,7 @@ def cpu_baseline(cfg, batch, steps):
     latent = torch.randn(batch, S)
     real = torch.randn(batch, 3, S, S).clamp(-1, 1)
     aug = torch.randn(batch, 3, S, S).clamp(-1, 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # the GPU box grants one GPU's share of host cores
     O.train_step(PG, PD, G.noise.clone(), og, od, latent, real, aug, ocfg)   # warm-up
     t0 = time.time()
     for _ in range(steps):
