@@ -60,10 +60,10 @@ class SpectralNormBatch:
         self._struct = struct.Struct("<8Q4i")
 
     def run(self):
-        """Power iteration for every layer; leaves (sigma, wv) on each layer for its next forward."""
+        """One power iteration for every layer (u, v advanced in place); returns this iteration's (sigma, wv)."""
         from ._lib import check, lib
         if not self.layers:
-            return
+            return None, None
         dev = self.layers[0].module.weight_bar.device
         if self._meta is None:
             self._build(dev)
@@ -94,6 +94,10 @@ class SpectralNormBatch:
         check(lib().locate_sn_power_iter_batched(self._table.data_ptr(), n, self.max_h, self.max_wd,
                                                  torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
         sig, wvs = self._sig.clone(), self._wvs.clone()   # this forward's sigma / W v (kept for its backward)
+        return sig, wvs
+
+    def assign(self, sig, wvs):
+        """Hand one power iteration's results to the layers (consumed by their next forward)."""
         hoff = 0
         for i, (sn, (h, _, _)) in enumerate(zip(self.layers, self._meta)):
             sn._pre = (sig[i], wvs[hoff:hoff + h])
@@ -103,11 +107,28 @@ class SpectralNormBatch:
 class _NetBase(nn.Module):
     batched_spectral_norm = False   # see SpectralNormBatch; off by default (per-layer update inside each layer)
 
+    def _batch(self):
+        if getattr(self, "_sn_batch", None) is None:
+            object.__setattr__(self, "_sn_batch", SpectralNormBatch(self))
+            object.__setattr__(self, "_sn_queue", [])
+        return self._sn_batch
+
+    def prefetch_spectral_norm(self, n_forwards):
+        """Run the power iterations of the next `n_forwards` forwards now, in order, on the current stream.  The
+        forwards themselves may then run concurrently on different streams: each consumes one queued result, exactly
+        the (u, v, sigma) sequence the reference produces by iterating at the start of every forward."""
+        b = self._batch()
+        for _ in range(n_forwards):
+            sig, wvs = b.run()
+            if sig is not None:
+                self._sn_queue.append((sig, wvs))
+
     def _sn_prologue(self):
         if self.batched_spectral_norm:
-            if getattr(self, "_sn_batch", None) is None:
-                object.__setattr__(self, "_sn_batch", SpectralNormBatch(self))
-            self._sn_batch.run()
+            b = self._batch()
+            sig, wvs = self._sn_queue.pop(0) if self._sn_queue else b.run()
+            if sig is not None:
+                b.assign(sig, wvs)
 
 
 class Generator(_NetBase):

@@ -384,7 +384,7 @@ def _panel(owner, w, geom, garr, adjoint):
     nbytes = L.locate_conv_panel_bytes(garr, adjoint)
     buf = hit[1] if (hit is not None and hit[1].numel() == max(nbytes, 16) and hit[1].device == w.device) else _ws(nbytes, w.device)
     check(L.locate_conv_pack_panel(garr, adjoint, _p(w), _p(buf), _stream()), "locate_conv_pack_panel")
-    cache[key] = (ver, buf)
+    cache[key] = (ver, buf, list(geom))
     return buf
 
 
@@ -448,6 +448,25 @@ def _finalize_pending_dv():
             v.grad = st["dv"]
         else:
             v.grad.add_(st["dv"])
+
+
+def refresh_panels(params):
+    """Re-pack, on the current stream, every cached weight panel of `params` whose weight has changed since it was
+    packed.  Needed before work that uses the same layers concurrently on several streams (the pack is otherwise done
+    lazily by the first user, on that user's stream)."""
+    L = lib()
+    for w in params:
+        cache = w.__dict__.get("_locate_panels")
+        if not cache:
+            continue
+        ver = w._version
+        for key, (pver, buf, geom) in list(cache.items()):
+            if pver != ver and buf.device == w.device:
+                wc = w.detach()
+                if not wc.is_contiguous():
+                    continue
+                check(L.locate_conv_pack_panel(_geom(geom), key[0], _p(wc), _p(buf), _stream()), "locate_conv_pack_panel")
+                cache[key] = (ver, buf, geom)
 
 
 def sn_power_iteration(w_bar, u, v):

@@ -42,21 +42,60 @@ def g_loss(d_fake):
 
 
 class TrainStep:
-    def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None):
+    def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None,
+                 concurrent_d=False):
         self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
         self.penalty_gamma = penalty_gamma
         self.minibatches = minibatches
         self.reducer_g, self.reducer_d = reducer_g, reducer_d
+        # concurrent_d: run the D-step's three discriminator passes (and the generator forward feeding the second)
+        # on three HIP streams.  Most of the step's ~1900 launches are tiny, launch-latency-bound kernels; three
+        # independent chains side by side fill the chip where one cannot.  Needs the batched spectral norm (the power
+        # iterations of the three forwards are done first, in the reference's order real / fake / augmented).
+        self.concurrent_d = concurrent_d
+        self._streams = None
 
     # ---- the four phases of one iteration (kept separate so that each can be its own hipGraph) --------------
+    def _d_forwards_concurrent(self, latent, real, aug):
+        from . import ops
+        gen, dis = self.gen, self.dis
+        if not (gen.batched_spectral_norm and dis.batched_spectral_norm):
+            raise RuntimeError("concurrent_d needs batched_spectral_norm on both networks")
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream() for _ in range(3)]
+        s_real, s_fake, s_aug = self._streams
+        # everything the three chains share is brought up to date on the main stream first
+        ops.refresh_panels([m.module.weight_bar for m in dis._batch().layers])
+        gen.prefetch_spectral_norm(1)
+        dis.prefetch_spectral_norm(3)              # sigma_1 (real), sigma_2 (fake), sigma_3 (augmented)
+        for s in self._streams:
+            s.wait_stream(main)
+        with torch.cuda.stream(s_real):
+            d_true = dis(real)                     # consumes sigma_1
+        with torch.cuda.stream(s_fake):
+            with torch.no_grad():
+                generated = gen(latent)
+            d_fake = dis(generated)                # consumes sigma_2
+        with torch.cuda.stream(s_aug):
+            d_aug = dis(aug)                       # consumes sigma_3
+        for s in self._streams:
+            main.wait_stream(s)
+        for t_ in (d_true, d_fake, d_aug, generated):
+            t_.record_stream(main)
+        return generated, d_true, d_fake, d_aug
+
     def d_forward_backward(self, latent, real, aug):
         gen, dis = self.gen, self.dis
-        with torch.no_grad():                      # main.py:146 builds a graph and drops it (.detach()); same values
-            generated = gen(latent)
         dis.zero_grad()                            # main.py:148
-        d_true = dis(real)                         # :149
-        d_fake = dis(generated)                    # :150 (the reference negates it; the loss kernel takes it raw)
-        d_aug = dis(aug)                           # grad_penalty.py:2
+        if self.concurrent_d:
+            generated, d_true, d_fake, d_aug = self._d_forwards_concurrent(latent, real, aug)
+        else:
+            with torch.no_grad():                  # main.py:146 builds a graph and drops it (.detach()); same values
+                generated = gen(latent)
+            d_true = dis(real)                     # :149
+            d_fake = dis(generated)                # :150 (the reference negates it; the loss kernel takes it raw)
+            d_aug = dis(aug)                       # grad_penalty.py:2
         losses, g_t, g_f, g_a = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
         if self.reducer_d is not None:
             self.reducer_d.begin()

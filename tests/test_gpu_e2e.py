@@ -33,7 +33,7 @@ def assert_step_close(got, want, lr, step, what):
     assert float(d.max()) <= 2.5 * lr, "%s: max |delta| = %.3e lr" % (what, float(d.max()) / lr)
 
 
-def _build_tiny(z, batched_sn=False):
+def _build_tiny(z, batched_sn=False, concurrent_d=False):
     from locate_amd import Discriminator, Generator, Nadam, NetConfig, TrainStep
     cfg = NetConfig(image_size=32, base_feature_factor=1)
     G, D = Generator(cfg), Discriminator(cfg)
@@ -44,14 +44,14 @@ def _build_tiny(z, batched_sn=False):
     G, D = G.to(dev), D.to(dev)
     G.batched_spectral_norm = D.batched_spectral_norm = batched_sn
     step = TrainStep(G, D, Nadam(G.parameters(), lr=cfg.glr, betas=(cfg.beta1, cfg.beta2)),
-                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)))
+                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), concurrent_d=concurrent_d)
     return cfg, G, D, step, dev
 
 
-@pytest.mark.parametrize("batched_sn", [False, True])
-def test_tiny_two_steps_golden(batched_sn):
+@pytest.mark.parametrize("batched_sn,concurrent_d", [(False, False), (True, False), (True, True)])
+def test_tiny_two_steps_golden(batched_sn, concurrent_d):
     z = load_golden("g8_tiny_e2e")
-    cfg, G, D, step, dev = _build_tiny(z, batched_sn)
+    cfg, G, D, step, dev = _build_tiny(z, batched_sn, concurrent_d)
     for it in (1, 2):
         p = "step%d/" % it
         # capture gradients and pre-step u/v through hooks on the optimizers' step
@@ -153,7 +153,7 @@ def test_graph_replay_equals_eager():
     from locate_amd.graph import GraphedTrainStep
     z = load_golden("g8_tiny_e2e")
     cfg, G1, D1, step1, dev = _build_tiny(z, True)
-    _, G2, D2, step2, _ = _build_tiny(z, True)
+    _, G2, D2, step2, _ = _build_tiny(z, True, concurrent_d=True)      # graphs capture the three-stream D-step
     lat, real, aug = (T(z["step1/" + k]).to(dev) for k in ("latent", "real", "aug"))
     runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations, then capture (no execution)
     for _ in range(2):
