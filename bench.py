@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial-d", action="store_true", help="run the three discriminator passes of the D-step on one stream")
+    ap.add_argument("--concurrent-d", action="store_true",
+                    help="run the three discriminator passes of the D-step on three streams (measured: no gain under "
+                         "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -132,7 +134,7 @@ def main():
         broadcast_module_state(D, 0)
         late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
         red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters(), late=late_v)
-    step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=not args.serial_d)
+    step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)
