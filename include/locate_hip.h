@@ -43,10 +43,16 @@ int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, 
  * additionally receives RootTanh(out) (the conv stage that follows starts with RootTanh, libs/conv.py:22-24) */
 int locate_norm_apply_fwd(const float* x, const float* stats, const float* scale, int scale_per_sample, const float* bias,
                           float* out, float* act_out, int B, int C, int hw, void* stream);
+/* fused forward in two launches: statistics + apply; with_act = 1 stores RootTanh(out) INSTEAD of out;
+ * stats_out = {mean, std}; workspace: locate_norm_stats_workspace_bytes() */
+int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out, int with_act,
+                    float* stats_out, int B, int C, int hw, void* workspace, void* stream);
 size_t locate_norm_bwd_workspace_bytes(int B, int C);
-/* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward) */
-int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample, float* dx,
-                    float* dscale, float* dbias, int B, int C, int hw, void* workspace, void* stream);
+/* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward); with_act = 1: g is the
+ * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out */
+int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample,
+                    const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw,
+                    void* workspace, void* stream);
 /* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
 int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream);
 

@@ -58,6 +58,26 @@ __global__ void __launch_bounds__(1024) stats_final_kernel(const double* __restr
     }
 }
 
+#define NORM_MAX_PARTIALS 512
+
+// mean / unbiased std from the per-block partial sums; every thread of the calling block gets the result
+// (fixed summation order: bit-identical in every block and on every replay)
+__device__ __forceinline__ void stats_from_partials(const double* __restrict__ partial, int nblocks, int64_t n, double* scratch,
+                                                    float& mean_out, float& std_out) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        s += partial[2 * i];
+        q += partial[2 * i + 1];
+    }
+    s = block_sum<double>(s, scratch);
+    q = block_sum<double>(q, scratch);
+    const double mean = s / (double)n;
+    double var = (q - s * mean) / (double)(n - 1);
+    if (var < 0.0) var = 0.0;
+    mean_out = (float)mean;
+    std_out = (float)sqrt(var);
+}
+
 LOCATE_API size_t locate_norm_stats_workspace_bytes(void) { return 2048 * 2 * sizeof(double); }
 
 LOCATE_API int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, void* stream) {
@@ -131,35 +151,126 @@ LOCATE_API int locate_norm_apply_fwd(const float* x, const float* stats, const f
     return LOCATE_OK;
 }
 
+// Fused forward: statistics partials (one launch) + apply (one launch; every block reduces the <= 512 partial pairs
+// itself instead of waiting for a third, single-block launch).  Block 0 publishes stats = {mean, std} for backward.
+template <bool ACT>
+__global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ partial,
+                                                               int npartial, float* __restrict__ stats_out,
+                                                               const float* __restrict__ scale, int scale_per_sample,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               float* __restrict__ act, int64_t planes, int C, int hw) {
+    __shared__ double scratch[16];
+    const int64_t n = planes * hw;
+    float mu, s;
+    stats_from_partials(partial, npartial, n, scratch, mu, s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats_out[0] = mu;
+        stats_out[1] = s;
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((hw & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        float4* a4 = reinterpret_cast<float4*>(act);
+        const int hw4 = hw >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+            const int64_t p = i / hw4;
+            const int c = (int)(p % C);
+            const float y = scale[scale_per_sample ? p : c], b = bias[c];
+            const float4 v = x4[i];
+            float4 o;
+            o.x = (v.x - mu) * y / s + b; o.y = (v.y - mu) * y / s + b;
+            o.z = (v.z - mu) * y / s + b; o.w = (v.w - mu) * y / s + b;
+            if (ACT) {
+                float4 r;
+                r.x = roottanh_f(o.x); r.y = roottanh_f(o.y); r.z = roottanh_f(o.z); r.w = roottanh_f(o.w);
+                a4[i] = r;
+            } else {
+                o4[i] = o;
+            }
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t p = i / hw;
+        const int c = (int)(p % C);
+        const float y = scale[scale_per_sample ? p : c];
+        const float o = (x[i] - mu) * y / s + bias[c];
+        if (ACT) act[i] = roottanh_f(o);
+        else out[i] = o;
+    }
+}
+
+// out = (x - mean(x)) * scale / std(x) + bias  (with_act = 0), or RootTanh of it (with_act = 1; the plain value is not
+// stored - backward recomputes it).  stats_out receives {mean, std}.  Two launches.
+LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out,
+                               int with_act, float* stats_out, int B, int C, int hw, void* workspace, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace && stats_out && out, "locate_norm_fwd: bad arguments");
+    LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_fwd: x must be 16-byte aligned");
+    const int64_t planes = (int64_t)B * C, n = planes * hw;
+    LOCATE_REQUIRE(n > 1, "locate_norm_fwd: needs at least two elements");
+    int np = stream_grid(n, 256 * 16);
+    if (np > NORM_MAX_PARTIALS) np = NORM_MAX_PARTIALS;
+    double* partial = static_cast<double*>(workspace);
+    stats_partial_kernel<<<np, 256, 0, as_stream(stream)>>>(x, n, partial);
+    LOCATE_LAUNCH_CHECK("locate_norm_fwd(stats)");
+    const int grid = stream_grid(n, 1024);
+    if (with_act)
+        norm_apply_fused_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(x, partial, np, stats_out, scale, scale_per_sample, bias,
+                                                                          nullptr, out, planes, C, hw);
+    else
+        norm_apply_fused_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(x, partial, np, stats_out, scale, scale_per_sample,
+                                                                           bias, out, nullptr, planes, C, hw);
+    LOCATE_LAUNCH_CHECK("locate_norm_fwd(apply)");
+    return LOCATE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 //   pass 1 (one wave per plane):   S1[p] = sum g,  S2[p] = sum (x - mu) g
 //   pass 2 (one block):            dbias[c], dscale, consts = { mean(y g / s), dz / ((N-1) s) }
 //   pass 3 (element-wise):         dx = y[p] g / s - consts[0] + consts[1] (x - mu)
 // ---------------------------------------------------------------------------------------------
+// ACT: g is the gradient w.r.t. RootTanh(out); go = g * RootTanh'(out) with out = (x - mu) * y / s + b recomputed
+template <bool ACT>
+__device__ __forceinline__ float norm_go(float xv, float gv, float mu, float s, float y, float b) {
+    if (!ACT) return gv;
+    const float o = (xv - mu) * y / s + b;
+    return roottanh_grad_f(o, gv);
+}
+
+template <bool ACT>
 __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                             const float* __restrict__ stats, float* __restrict__ S1,
-                                                             float* __restrict__ S2, int64_t planes, int hw) {
-    const float mu = stats[0];
+                                                             const float* __restrict__ stats, const float* __restrict__ scale,
+                                                             int scale_per_sample, const float* __restrict__ bias, int C,
+                                                             float* __restrict__ S1, float* __restrict__ S2, int64_t planes,
+                                                             int hw) {
+    const float mu = stats[0], sd = stats[1];
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t p = wave; p < planes; p += nwaves) {
         const int64_t base = p * hw;
+        const int c = (int)(p % C);
+        const float y = ACT ? scale[scale_per_sample ? p : c] : 0.0f, b = ACT ? bias[c] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
         if ((hw & 3) == 0) {
             const float4* x4 = reinterpret_cast<const float4*>(x + base);
             const float4* g4 = reinterpret_cast<const float4*>(g + base);
             for (int i = lane; i < (hw >> 2); i += 64) {
-                const float4 xv = x4[i], gv = g4[i];
+                const float4 xv = x4[i];
+                float4 gv = g4[i];
+                gv.x = norm_go<ACT>(xv.x, gv.x, mu, sd, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, sd, y, b);
+                gv.z = norm_go<ACT>(xv.z, gv.z, mu, sd, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, sd, y, b);
                 s1 += (gv.x + gv.y) + (gv.z + gv.w);
                 s2 += ((xv.x - mu) * gv.x + (xv.y - mu) * gv.y) + ((xv.z - mu) * gv.z + (xv.w - mu) * gv.w);
             }
         } else {
             for (int i = lane; i < hw; i += 64) {
-                const float gv = g[base + i];
+                const float xv = x[base + i];
+                const float gv = norm_go<ACT>(xv, g[base + i], mu, sd, y, b);
                 s1 += gv;
-                s2 = fmaf(x[base + i] - mu, gv, s2);
+                s2 = fmaf(xv - mu, gv, s2);
             }
         }
         s1 = wave_sum(s1);
@@ -222,10 +333,12 @@ __global__ void __launch_bounds__(1024) norm_bwd_final_kernel(const float* __res
     }
 }
 
+template <bool ACT>
 __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ stats, const float* __restrict__ scale,
-                                                          int scale_per_sample, const float* __restrict__ consts,
-                                                          float* __restrict__ dx, int64_t planes, int C, int hw) {
+                                                          int scale_per_sample, const float* __restrict__ bias,
+                                                          const float* __restrict__ consts, float* __restrict__ dx,
+                                                          int64_t planes, int C, int hw) {
     const float mu = stats[0], s = stats[1];
     const float m = consts[0], k = consts[1];
     const int64_t n = planes * hw;
@@ -237,8 +350,12 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         const int hw4 = hw >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
             const int64_t p = i / hw4;
-            const float y = scale[scale_per_sample ? p : (int)(p % C)];
-            const float4 xv = x4[i], gv = g4[i];
+            const int c = (int)(p % C);
+            const float y = scale[scale_per_sample ? p : c], b = ACT ? bias[c] : 0.0f;
+            const float4 xv = x4[i];
+            float4 gv = g4[i];
+            gv.x = norm_go<ACT>(xv.x, gv.x, mu, s, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, s, y, b);
+            gv.z = norm_go<ACT>(xv.z, gv.z, mu, s, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, s, y, b);
             float4 o;
             o.x = y * gv.x / s - m + k * (xv.x - mu); o.y = y * gv.y / s - m + k * (xv.y - mu);
             o.z = y * gv.z / s - m + k * (xv.z - mu); o.w = y * gv.w / s - m + k * (xv.w - mu);
@@ -248,8 +365,10 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t p = i / hw;
-        const float y = scale[scale_per_sample ? p : (int)(p % C)];
-        dx[i] = y * g[i] / s - m + k * (x[i] - mu);
+        const int c = (int)(p % C);
+        const float y = scale[scale_per_sample ? p : c];
+        const float gv = norm_go<ACT>(x[i], g[i], mu, s, y, ACT ? bias[c] : 0.0f);
+        dx[i] = y * gv / s - m + k * (x[i] - mu);
     }
 }
 
@@ -258,23 +377,33 @@ LOCATE_API size_t locate_norm_bwd_workspace_bytes(int B, int C) {
 }
 
 // dscale: [C] (scale_per_sample = 0) or [B*C];  dbias: [C].  Both overwritten.
+// with_act = 1: g is the gradient w.r.t. RootTanh(norm(x)) (the fused forward of locate_norm_fwd); the activation's
+// derivative is applied on the fly from the recomputed norm output, so neither that output nor a separate
+// RootTanh-backward pass exists.
 LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale,
-                               int scale_per_sample, float* dx, float* dscale, float* dbias, int B, int C, int hw,
-                               void* workspace, void* stream) {
+                               int scale_per_sample, const float* bias, int with_act, float* dx, float* dscale, float* dbias,
+                               int B, int C, int hw, void* workspace, void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd: bad shape or missing workspace");
+    LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd: with_act needs the bias");
     const int64_t planes = (int64_t)B * C;
     float* S1 = static_cast<float*>(workspace);
     float* S2 = S1 + planes;
     float* consts = S2 + planes;
     int64_t blocks = cdiv64(planes, 4);
     if (blocks > 4096) blocks = 4096;
-    norm_bwd_plane_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(x, g, stats, S1, S2, planes, hw);
+    hipStream_t st = as_stream(stream);
+    if (with_act)
+        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, hw);
+    else
+        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(plane)");
-    norm_bwd_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts,
-                                                            B, C, hw);
+    norm_bwd_final_kernel<<<1, 1024, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts, B, C, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
-    norm_bwd_dx_kernel<<<stream_grid(planes * hw, 1024), 256, 0, as_stream(stream)>>>(x, g, stats, scale, scale_per_sample,
-                                                                                      consts, dx, planes, C, hw);
+    const int grid = stream_grid(planes * hw, 1024);
+    if (with_act)
+        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes, C, hw);
+    else
+        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes, C, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
     return LOCATE_OK;
 }

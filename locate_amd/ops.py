@@ -85,8 +85,8 @@ tanh = TanhFn.apply
 # InPlaceNorm
 # ------------------------------------------------------------------------------------------------
 class InPlaceNormFn(torch.autograd.Function):
-    """out = (x - mean(x)) * scale / std(x) + bias with global scalar statistics.  With `with_act` the
-    forward returns RootTanh(out) instead (out is kept only for the backward)."""
+    """out = (x - mean(x)) * scale / std(x) + bias with global scalar statistics.  With `with_act` the forward
+    returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
     def forward(ctx, x, scale, bias, with_act):
@@ -101,17 +101,12 @@ class InPlaceNormFn(torch.autograd.Function):
         st = _stream()
         stats = torch.empty(2, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device)
-        check(L.locate_norm_stats(_p(x), x.numel(), _p(stats), _p(ws), st), "locate_norm_stats")
-        out = torch.empty_like(x)
-        act = torch.empty_like(x) if with_act else None
-        check(L.locate_norm_apply_fwd(_p(x), _p(stats), _p(scale_c), int(per_sample), _p(bias_c), _p(out), _p(act), B, C, hw,
-                                      st), "locate_norm_apply_fwd")
-        ctx.per_sample, ctx.with_act = per_sample, with_act
+        out = torch.empty_like(x)       # RootTanh(norm(x)) when with_act, else norm(x)
+        check(L.locate_norm_fwd(_p(x), _p(scale_c), int(per_sample), _p(bias_c), _p(out), int(bool(with_act)), _p(stats), B, C, hw,
+                                _p(ws), st), "locate_norm_fwd")
+        ctx.per_sample, ctx.with_act = per_sample, bool(with_act)
         ctx.scale_shape, ctx.bias_shape = scale.shape, bias.shape
-        if with_act:
-            ctx.save_for_backward(x, scale_c, stats, out)
-            return act
-        ctx.save_for_backward(x, scale_c, stats)
+        ctx.save_for_backward(x, scale_c, bias_c, stats)
         return out
 
     @staticmethod
@@ -119,21 +114,15 @@ class InPlaceNormFn(torch.autograd.Function):
         L = lib()
         st = _stream()
         g = _c(g)
-        if ctx.with_act:
-            x, scale, stats, out = ctx.saved_tensors
-            g_out = torch.empty_like(g)
-            check(L.locate_roottanh_bwd(_p(out), _p(g), _p(g_out), g.numel(), st), "locate_roottanh_bwd")
-            g = g_out
-        else:
-            x, scale, stats = ctx.saved_tensors
+        x, scale, bias, stats = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
         dx = torch.empty_like(x)
         dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device)
         dbias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
-        check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(dx), _p(dscale), _p(dbias), B, C, hw,
-                                _p(ws), st), "locate_norm_bwd")
+        check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
+                                _p(dscale), _p(dbias), B, C, hw, _p(ws), st), "locate_norm_bwd")
         return dx, dscale, dbias, None
 
 
@@ -312,13 +301,10 @@ class CatChannelsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = _c(g)
+        # channel slices of the incoming gradient, as views: the conv kernels consume batch-strided operands in place,
+        # everything else copies only if it has to
         ca, cb = ctx.split
-        ga = torch.empty((g.shape[0], ca) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
-        gb = torch.empty((g.shape[0], cb) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
-        _copy_channels(g[:, :ca], ga)
-        _copy_channels(g[:, ca:], gb)
-        return ga, gb
+        return g[:, :ca], g[:, ca:]
 
 
 cat_channels = CatChannelsFn.apply
