@@ -39,19 +39,19 @@ int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void*
  *      (libs/inplace_norm.py:4-45).  stats = {mean, std}. ---- */
 size_t locate_norm_stats_workspace_bytes(void);
 int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, void* stream);
-/* out = (x - mean) * scale / std + bias; scale is [C] (scale_per_sample = 0) or [B*C]; act_out (nullable)
- * additionally receives RootTanh(out) (the conv stage that follows starts with RootTanh, libs/conv.py:22-24) */
-int locate_norm_apply_fwd(const float* x, const float* stats, const float* scale, int scale_per_sample, const float* bias,
-                          float* out, float* act_out, int B, int C, int hw, void* stream);
-/* fused forward in two launches: statistics + apply; with_act = 1 stores RootTanh(out) INSTEAD of out;
- * stats_out = {mean, std}; workspace: locate_norm_stats_workspace_bytes() */
+/* fused forward in two launches (statistics + apply): out = (x - mean) * scale / std + bias; scale is [C]
+ * (scale_per_sample = 0) or [B*C]; with_act = 1 stores RootTanh(out) INSTEAD of out (the conv stage that follows starts
+ * with RootTanh, libs/conv.py:22-24).  groups > 1: the batch stacks `groups` independent forward calls of B/groups
+ * samples each (the three discriminator passes of main.py:149-152), every one with its OWN mean/std.
+ * stats_out = groups x {mean, std}; workspace: locate_norm_stats_workspace_bytes() */
 int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out, int with_act,
-                    float* stats_out, int B, int C, int hw, void* workspace, void* stream);
+                    float* stats_out, int B, int C, int hw, int groups, void* workspace, void* stream);
 size_t locate_norm_bwd_workspace_bytes(int B, int C);
 /* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward); with_act = 1: g is the
- * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out */
+ * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out;
+ * dscale / dbias sum over all groups (the reference accumulates the three passes' gradients, main.py:153-157) */
 int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample,
-                    const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw,
+                    const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw, int groups,
                     void* workspace, void* stream);
 /* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
 int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream);
@@ -93,6 +93,16 @@ int locate_sn_power_iter_batched(const void* table, int n_layers, int max_h, int
  * dsigma_out[0] = dsigma (nullable).  u, v are the CURRENT state (the reference's autograd sees the latest .data). */
 int locate_sn_weight_bwd(const double* inner_partial, int n_partial, const float* u, const float* v, const float* sigma,
                          const float* wv, float* gw, float* du, float* dsigma_out, int h, int wd, void* stream);
+/* the same for `groups` (<= 4) forward calls stacked along the batch of ONE layer call, each with its own sigma_k, v_k
+ * (the reference runs them one after the other, main.py:149-152): gw enters as sum_k G_k/sigma_k (locate_conv_wgrad
+ * with group scaling); dsigma_k = -<gy_k, y_k - bias>/sigma_k  (= -<G_k, W_bar>/sigma_k^2 taken on the activation side);
+ * gw += (sum_k dsigma_k) u v^T; du = sum_k dsigma_k W v_k; dsigma_total_out = sum_k dsigma_k.
+ * sigma_tab: {sigma_k, 1/sigma_k} pairs sigma_stride floats apart; wv rows wv_stride floats apart. */
+size_t locate_sn_group_workspace_bytes(void);
+int locate_sn_weight_bwd_grouped(const float* gy, int64_t gy_bs, const float* y, int64_t y_bs, const float* bias, int groups,
+                                 int Bg, int M, int plane, const float* sigma_tab, int sigma_stride, const float* u,
+                                 const float* v, const float* wv, int64_t wv_stride, float* gw, float* du,
+                                 float* dsigma_total_out, int h, int wd, void* workspace, void* stream);
 /* dv = (sum of the layer's 4 dsigma slots) * W^T u for all layers of `table` (records as for
  * locate_sn_power_iter_batched; field v = dv output, field sigma = the 4 slots, cleared afterwards) */
 int locate_sn_dv_batched(const void* table, int n_layers, int max_h, int max_wd, void* stream);
@@ -106,19 +116,25 @@ int locate_sn_dv_batched(const void* table, int n_layers, int max_h, int max_wd,
 size_t locate_conv_panel_bytes(const int* geom, int adjoint);
 int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* panel, void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
-int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale, const float* bias,
-                    float* y, int64_t y_bs, void* workspace, void* stream);
+/* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride] */
+int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
+                    int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
+                    void* stream);
 /* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
-int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale, const float* bias,
-                      float* gx, int64_t gx_bs, void* workspace, void* stream);
+int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
+                      int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
+                      void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
- * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable. */
+ * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.
+ * scale_group_batch > 0: gy of batch element b is weighted by inv_scale[(b / scale_group_batch) * scale_stride] instead
+ * (gw = sum_k G_k / sigma_k over stacked forward calls; <= 4 groups; w_ref and inner_partial must be null). */
 size_t locate_conv_wgrad_workspace_bytes(const int* geom);
 int locate_conv_wgrad_partials(const int* geom);
 int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
-                      const float* w_ref, const float* inv_scale, double* inner_partial, void* workspace, void* stream);
+                      const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
+                      double* inner_partial, void* workspace, void* stream);
 
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */

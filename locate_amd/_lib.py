@@ -30,10 +30,9 @@ PROTOTYPES = {
     "locate_tanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "locate_norm_stats_workspace_bytes": (c_sz, []),
     "locate_norm_stats": (c_i, [c_p, c_i64, c_p, c_p, c_p]),
-    "locate_norm_apply_fwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "locate_norm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
-    "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
-    "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "locate_channel_sum": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_p]),
     "locate_gate_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "locate_gate_bwd_workspace_bytes": (c_sz, [c_i64]),
@@ -52,16 +51,19 @@ PROTOTYPES = {
     "locate_sn_table_record_bytes": (c_sz, []),
     "locate_sn_power_iter_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_sn_weight_bwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "locate_sn_group_workspace_bytes": (c_sz, []),
+    "locate_sn_weight_bwd_grouped": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i64, c_p,
+                                           c_p, c_p, c_i, c_i, c_p, c_p]),
     "locate_sn_dv_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_conv_panel_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
-    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
     "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),

@@ -137,7 +137,9 @@ struct IgParams {
     const float* in;
     float* out;
     const float* bias;   // [M] or null
-    const float* scale;  // device scalar multiplying the contraction (1/sigma of spectral norm) or null
+    const float* scale;  // multiplies the contraction (1/sigma of spectral norm) or null; one value, or one per GROUP of
+    int scale_bg;        //   scale_bg consecutive batch elements (scale_bg = 0: a single value), scale_stride floats apart
+    int scale_stride;
     long long in_bs, out_bs;
     int B, C, H, W;      // gathered tensor: C = reduction channels
     int M, OH, OW;       // produced tensor
@@ -299,17 +301,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    const float out_scale = p.scale ? p.scale[0] : 1.0f;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
     const bool split = p.ksplit > 1;
     const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
+    float col_scale[TN];           // 1/sigma of the column's group (the batch may stack several forwards)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nj = n0 + (wn * TN + j) * 32 + lcol;
         const int nn = nj < N ? nj : 0;
         const int qhw = ph.QH * ph.QW;
         const int b = nn / qhw, q = nn - b * qhw;
+        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
         const int qy = q / ph.QW, qx = q - qy * ph.QW;
         const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
         const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], out_scale, bias_v[r]);
+                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
             }
         }
     }
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
-                                                                int B, int M, int plane,
+                                                                int scale_bg, int scale_stride, int B, int M, int plane,
                                                                 long long out_bs, long long slab_stride, int ksplit) {
     const long long per_b = (long long)M * plane;
     const long long total = (long long)B * per_b;
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
         const long long b = i / per_b, r = i - b * per_b;
         float acc = 0.0f;
         for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
-        if (scale) acc *= scale[0];
+        if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
         if (bias) acc += bias[(int)(r / plane)];
         out[b * out_bs + r] = acc;
     }
@@ -399,7 +402,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
-        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.B, p.M, p.OH * p.OW, p.out_bs,
+        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
                                                                          p.slab_stride, p.ksplit);
         LOCATE_LAUNCH_CHECK(who);
     }
@@ -531,12 +534,15 @@ LOCATE_API int locate_conv_pack_panel(const int* geom, int adjoint, const float*
 }
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
-                     const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st, const char* who) {
+                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st,
+                     const char* who) {
     IgParams p;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
+    p.scale_bg = scale_bg; p.scale_stride = scale_stride;
+    LOCATE_REQUIRE(scale_bg >= 0 && (scale_bg == 0 || g.B % scale_bg == 0), "%s: batch %d is not a multiple of the scale group %d", who, g.B, scale_bg);
     LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
     return launch_igemm(p, nmax, ws, st, who);
 }
@@ -552,27 +558,31 @@ static size_t igemm_ws_bytes(const int* geom, int adjoint) {
 LOCATE_API size_t locate_conv_fwd_workspace_bytes(const int* geom) { return igemm_ws_bytes(geom, 0); }
 LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) { return igemm_ws_bytes(geom, 1); }
 
-// y[b, m, oh, ow] = bias[m] + scale * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]     (panel: adjoint = 0)
+// y[b, m, oh, ow] = bias[m] + scale_g(b) * sum w[m, c, kh, kw] x[b, c, oh*s-ph+kh, ow*s-pw+kw]     (panel: adjoint = 0)
 // x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
+// scale (nullable): scale_group_batch = 0 -> one device scalar; > 0 -> batch element b uses
+// scale[(b / scale_group_batch) * scale_stride] (several forwards stacked along the batch, each with its own sigma).
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
-                               const float* bias, float* y, int64_t y_bs, void* workspace, void* stream) {
+                               int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
+                               void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
-    return run_igemm(g, 0, x, x_bs, panel, scale, bias, y, y_bs, static_cast<float*>(workspace), as_stream(stream),
-                     "locate_conv_fwd");
+    return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
+                     as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
 // (data adjoint of R; also the FORWARD of ConvTranspose2d with weight [C_in = M, C_out = C, KH, KW]; panel: adjoint = 1).
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
-                                 const float* bias, float* gx, int64_t gx_bs, void* workspace, void* stream) {
+                                 int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
+                                 void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
-    return run_igemm(g, 1, gy, gy_bs, panel, scale, bias, gx, gx_bs, static_cast<float*>(workspace), as_stream(stream),
-                     "locate_conv_dgrad");
+    return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
+                     static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,6 +604,9 @@ struct WgParams {
     unsigned q_mul, ow_mul;   // division by Q = OH*OW and by OW as multiply-high + shifts (see fastdiv)
     int q_s1, q_s2, ow_s1, ow_s2;
     // single-split launches finish in the epilogue (no slab, no reduce kernel):
+    int gscale_bg, gscale_stride;   // > 0: gy of batch element b is multiplied by inv_scale[(b / gscale_bg) * gscale_stride]
+                              // while it is loaded (stacked forwards with different sigma); inv_scale then is NOT
+                              // applied in the epilogue
     float* direct_out;        // gw, or null when slabs are used
     const float* w_ref;       // W_bar for the fused <G, W_bar> partial sums (nullable)
     const float* inv_scale;   // device scalar 1/sigma (nullable)
@@ -670,6 +683,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         xoff[i] = rt_off[rl];
         xdyx[i] = ((int)rt_dy[rl] & 0xffff) | ((int)rt_dx[rl] << 16);
     }
+    // group scales (at most 4 groups) live in registers; gsc = the scale of the tile currently held in greg[]
+    float gs0 = 1.0f, gs1 = 1.0f, gs2 = 1.0f, gs3 = 1.0f, gsc = 1.0f;
+    if (p.gscale_bg > 0) {
+        const int ng = p.B / p.gscale_bg;
+        gs0 = p.inv_scale[0];
+        gs1 = ng > 1 ? p.inv_scale[p.gscale_stride] : 1.0f;
+        gs2 = ng > 2 ? p.inv_scale[2 * p.gscale_stride] : 1.0f;
+        gs3 = ng > 3 ? p.inv_scale[3 * p.gscale_stride] : 1.0f;
+    }
     auto load_tiles = [&](int nb) {
         const int n = nb + nl;
         const bool ok = n < n_end;
@@ -677,6 +699,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         const int b = fastdiv(nn, p.q_mul, p.q_s1, p.q_s2), q = nn - b * Q;
         const int oh = fastdiv(q, p.ow_mul, p.ow_s1, p.ow_s2), ow = q - oh * p.OW;
         const float* gp = p.gy + (long long)b * p.gy_bs + q;
+        if (p.gscale_bg > 0) {
+            const int grp = b / p.gscale_bg;
+            gsc = grp == 0 ? gs0 : grp == 1 ? gs1 : grp == 2 ? gs2 : gs3;
+        }
         gmask = 0;
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
@@ -700,7 +726,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < G_PT; ++i) Gs[buf][nl][sub + 8 * i] = ((gmask >> i) & 1u) ? greg[i] : 0.0f;
+        for (int i = 0; i < G_PT; ++i) Gs[buf][nl][sub + 8 * i] = ((gmask >> i) & 1u) ? greg[i] * gsc : 0.0f;
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) Xs[buf][nl][sub + 8 * i] = ((xmask >> i) & 1u) ? xreg[i] : 0.0f;
     };
@@ -736,7 +762,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
     __shared__ double red[4];
     const bool direct = p.direct_out != nullptr;
     float* dst = direct ? p.direct_out : p.slab + (long long)blockIdx.z * p.M * p.R;
-    const float sc = (direct && p.inv_scale) ? p.inv_scale[0] : 1.0f;
+    const float sc = (direct && p.inv_scale && p.gscale_bg == 0) ? p.inv_scale[0] : 1.0f;
     double dot = 0.0;
     const bool want_dot = direct && p.w_ref != nullptr;
 #pragma unroll
@@ -855,13 +881,17 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
 // gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw]          (overwritten)
 // With w_ref (= W_bar, same layout as gw) and inner_partial: the partial sums of <UNSCALED gw, W_bar> the
 // spectral-norm backward needs come out of the same pass (locate_conv_wgrad_partials(geom) doubles).
+// scale_group_batch > 0: gy of batch element b is weighted by inv_scale[(b / scale_group_batch) * scale_stride] instead
+// (stacked forwards; at most 4 groups; w_ref / inner_partial must then be null - see locate_sn_group_dsigma).
 LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
-                                 const float* w_ref, const float* inv_scale, double* inner_partial, void* workspace,
-                                 void* stream) {
+                                 const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
+                                 double* inner_partial, void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
     LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
     LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
+    LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
+                   g.B / scale_group_batch <= 4 && !w_ref && !inner_partial)), "locate_conv_wgrad: bad group scaling arguments");
     hipStream_t st = as_stream(stream);
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
@@ -874,9 +904,11 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     fastdiv_make((unsigned)(g.OH * g.OW), &p.q_mul, &p.q_s1, &p.q_s2);
     fastdiv_make((unsigned)g.OW, &p.ow_mul, &p.ow_s1, &p.ow_s2);
     const bool direct = nsplit == 1;
+    const bool grouped = scale_group_batch > 0;
+    p.gscale_bg = scale_group_batch; p.gscale_stride = scale_stride;
     p.direct_out = direct ? gw : nullptr;
     p.w_ref = direct ? w_ref : nullptr;
-    p.inv_scale = direct ? inv_scale : nullptr;
+    p.inv_scale = (direct || grouped) ? inv_scale : nullptr;
     p.partial = direct ? inner_partial : nullptr;
     dim3 grid((p.R + 127) / 128, (g.M + bm - 1) / bm, nsplit);
     if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
@@ -888,9 +920,9 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         const int64_t n = (int64_t)g.M * p.R;
         const int rg = wgrad_reduce_grid(n, nsplit);
         if (wgrad_reduce_zp(nsplit, n) == 4)
-            slab_reduce_kernel<4><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
+            slab_reduce_kernel<4><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
         else
-            slab_reduce_kernel<1><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, inv_scale, inner_partial);
+            slab_reduce_kernel<1><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
     }
     return LOCATE_OK;

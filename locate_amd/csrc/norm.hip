@@ -5,19 +5,26 @@
 // Backward (closed form of the reference's MeanSubMulDivAdd.backward + ATen std backward):
 //     dx = y g / s - mean(y g / s) + dz (x - mu) / ((N-1) s),   dz = -sum((x-mu) g y) / s^2
 //     dy = sum_bcast (x - mu) g / s,    db = sum_bcast g
-// All HBM-bound.  Statistics are accumulated in fp64 (the fp64 VALU rate is far above what an
-// 8 TB/s stream needs) so the result does not depend on the grid shape.
+// GROUPS: the batch may hold `groups` independent forwards stacked along B (the discriminator's real / fake /
+// augmented passes of one D-step run as ONE pass of batch 3B); statistics, and everything derived from them, are
+// then per group (what three separate reference forwards compute), parameter gradients sum over all groups.
+// All HBM-bound.  Statistics are accumulated in fp64 in a fixed order (no atomics: bit-reproducible).
 #include "common.h"
 
+#define NORM_MAX_PARTIALS 512
+#define NORM_MAX_GROUPS 4
+
 // ---------------------------------------------------------------------------------------------
-// statistics: partial (sum, sum of squares) per block in double, then one finalising block
+// statistics: partial (sum, sum of squares) per block in double; blockIdx.y = group
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) stats_partial_kernel(const float* __restrict__ x, int64_t n,
+__global__ void __launch_bounds__(256) stats_partial_kernel(const float* __restrict__ x, int64_t n_group,
                                                             double* __restrict__ partial) {
     __shared__ double scratch[16];
+    x += (int64_t)blockIdx.y * n_group;
+    partial += (int64_t)blockIdx.y * 2 * gridDim.x;
     double s = 0.0, q = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n4 = n >> 2;
+    const int64_t n4 = n_group >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = x4[i];
@@ -25,7 +32,7 @@ __global__ void __launch_bounds__(256) stats_partial_kernel(const float* __restr
         s += (a + b) + (c + d);
         q += (a * a + b * b) + (c * c + d * d);
     }
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_group; i += stride) {
         const double a = x[i];
         s += a;
         q += a * a;
@@ -37,28 +44,6 @@ __global__ void __launch_bounds__(256) stats_partial_kernel(const float* __restr
         partial[2 * blockIdx.x + 1] = q;
     }
 }
-
-// stats[0] = mean, stats[1] = unbiased std (torch.Tensor.std default), both fp32
-__global__ void __launch_bounds__(1024) stats_final_kernel(const double* __restrict__ partial, int nblocks, int64_t n,
-                                                           float* __restrict__ stats) {
-    __shared__ double scratch[16];
-    double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
-        s += partial[2 * i];
-        q += partial[2 * i + 1];
-    }
-    s = block_sum<double>(s, scratch);
-    q = block_sum<double>(q, scratch);
-    if (threadIdx.x == 0) {
-        const double mean = s / (double)n;
-        double var = (q - s * mean) / (double)(n - 1);
-        if (var < 0.0) var = 0.0;
-        stats[0] = (float)mean;
-        stats[1] = (float)sqrt(var);
-    }
-}
-
-#define NORM_MAX_PARTIALS 512
 
 // mean / unbiased std from the per-block partial sums; every thread of the calling block gets the result
 // (fixed summation order: bit-identical in every block and on every replay)
@@ -78,160 +63,117 @@ __device__ __forceinline__ void stats_from_partials(const double* __restrict__ p
     std_out = (float)sqrt(var);
 }
 
-LOCATE_API size_t locate_norm_stats_workspace_bytes(void) { return 2048 * 2 * sizeof(double); }
+__global__ void __launch_bounds__(256) stats_final_kernel(const double* __restrict__ partial, int nblocks, int64_t n,
+                                                          float* __restrict__ stats) {
+    __shared__ double scratch[16];
+    float mu, sd;
+    stats_from_partials(partial, nblocks, n, scratch, mu, sd);
+    if (threadIdx.x == 0) {
+        stats[0] = mu;
+        stats[1] = sd;
+    }
+}
 
+LOCATE_API size_t locate_norm_stats_workspace_bytes(void) { return (size_t)NORM_MAX_GROUPS * NORM_MAX_PARTIALS * 2 * sizeof(double); }
+
+// stats = {mean, unbiased std} of x[0..n)
 LOCATE_API int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, void* stream) {
-    LOCATE_REQUIRE(n > 0 && workspace && stats, "locate_norm_stats: empty input or missing buffers");
+    LOCATE_REQUIRE(n > 1 && workspace && stats, "locate_norm_stats: needs >= 2 elements and both buffers");
     LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_stats: x must be 16-byte aligned");
-    const int grid = stream_grid(n, 256 * 16);
+    int np = stream_grid(n, 256 * 16);
+    if (np > NORM_MAX_PARTIALS) np = NORM_MAX_PARTIALS;
     double* partial = static_cast<double*>(workspace);
-    stats_partial_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, n, partial);
+    stats_partial_kernel<<<np, 256, 0, as_stream(stream)>>>(x, n, partial);
     LOCATE_LAUNCH_CHECK("locate_norm_stats(partial)");
-    stats_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(partial, grid, n, stats);
+    stats_final_kernel<<<1, 256, 0, as_stream(stream)>>>(partial, np, n, stats);
     LOCATE_LAUNCH_CHECK("locate_norm_stats(final)");
     return LOCATE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// apply: out = (x - mu) * y[p] / s + b[c];  optional second output act = RootTanh(out)
-//   (the DeepResidualConv that follows every block-input norm starts with RootTanh, conv.py:22-24)
+// forward: statistics partials (one launch) + apply (one launch; every block reduces its group's <= 512 partial
+// pairs itself instead of waiting for a third, single-block launch).  blockIdx.y = group; the first block of a group
+// publishes stats[group] = {mean, std} for backward.  ACT: store RootTanh(out) instead of out (the conv stage that
+// follows a block-input norm starts with RootTanh, conv.py:22-24).
 // ---------------------------------------------------------------------------------------------
-template <bool ACT>
-__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                         const float* __restrict__ scale, int scale_per_sample,
-                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                         float* __restrict__ act, int64_t planes, int C, int hw) {
-    const float mu = stats[0], s = stats[1];
-    const int64_t n = planes * hw;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if ((hw & 3) == 0) {
-        const float4* x4 = reinterpret_cast<const float4*>(x);
-        float4* o4 = reinterpret_cast<float4*>(out);
-        float4* a4 = reinterpret_cast<float4*>(act);
-        const int hw4 = hw >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
-            const int64_t p = i / hw4;
-            const int c = (int)(p % C);
-            const float y = scale[scale_per_sample ? p : c], b = bias[c];
-            const float4 v = x4[i];
-            float4 o;
-            o.x = (v.x - mu) * y / s + b; o.y = (v.y - mu) * y / s + b;
-            o.z = (v.z - mu) * y / s + b; o.w = (v.w - mu) * y / s + b;
-            o4[i] = o;
-            if (ACT) {
-                float4 r;
-                r.x = roottanh_f(o.x); r.y = roottanh_f(o.y); r.z = roottanh_f(o.z); r.w = roottanh_f(o.w);
-                a4[i] = r;
-            }
-        }
-        return;
-    }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t p = i / hw;
-        const int c = (int)(p % C);
-        const float y = scale[scale_per_sample ? p : c];
-        const float o = (x[i] - mu) * y / s + bias[c];
-        out[i] = o;
-        if (ACT) act[i] = roottanh_f(o);
-    }
-}
-
-LOCATE_API int locate_norm_apply_fwd(const float* x, const float* stats, const float* scale, int scale_per_sample,
-                                     const float* bias, float* out, float* act_out, int B, int C, int hw, void* stream) {
-    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0, "locate_norm_apply_fwd: bad shape");
-    const int64_t planes = (int64_t)B * C;
-    const int grid = stream_grid(planes * hw, 1024);
-    if (act_out)
-        norm_apply_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(x, stats, scale, scale_per_sample, bias, out, act_out,
-                                                                    planes, C, hw);
-    else
-        norm_apply_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(x, stats, scale, scale_per_sample, bias, out, nullptr,
-                                                                     planes, C, hw);
-    LOCATE_LAUNCH_CHECK("locate_norm_apply_fwd");
-    return LOCATE_OK;
-}
-
-// Fused forward: statistics partials (one launch) + apply (one launch; every block reduces the <= 512 partial pairs
-// itself instead of waiting for a third, single-block launch).  Block 0 publishes stats = {mean, std} for backward.
 template <bool ACT>
 __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ partial,
                                                                int npartial, float* __restrict__ stats_out,
                                                                const float* __restrict__ scale, int scale_per_sample,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               float* __restrict__ act, int64_t planes, int C, int hw) {
+                                                               int64_t planes_g, int C, int hw) {
     __shared__ double scratch[16];
-    const int64_t n = planes * hw;
+    const int grp = blockIdx.y;
+    const int64_t n = planes_g * hw;                 // elements of one group
     float mu, s;
-    stats_from_partials(partial, npartial, n, scratch, mu, s);
+    stats_from_partials(partial + (int64_t)grp * 2 * npartial, npartial, n, scratch, mu, s);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        stats_out[0] = mu;
-        stats_out[1] = s;
+        stats_out[2 * grp] = mu;
+        stats_out[2 * grp + 1] = s;
     }
+    x += (int64_t)grp * n;
+    out += (int64_t)grp * n;
+    const int64_t plane0 = (int64_t)grp * planes_g;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if ((hw & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x);
         float4* o4 = reinterpret_cast<float4*>(out);
-        float4* a4 = reinterpret_cast<float4*>(act);
         const int hw4 = hw >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
-            const int64_t p = i / hw4;
+            const int64_t p = plane0 + i / hw4;
             const int c = (int)(p % C);
             const float y = scale[scale_per_sample ? p : c], b = bias[c];
             const float4 v = x4[i];
             float4 o;
             o.x = (v.x - mu) * y / s + b; o.y = (v.y - mu) * y / s + b;
             o.z = (v.z - mu) * y / s + b; o.w = (v.w - mu) * y / s + b;
-            if (ACT) {
-                float4 r;
-                r.x = roottanh_f(o.x); r.y = roottanh_f(o.y); r.z = roottanh_f(o.z); r.w = roottanh_f(o.w);
-                a4[i] = r;
-            } else {
-                o4[i] = o;
-            }
+            if (ACT) { o.x = roottanh_f(o.x); o.y = roottanh_f(o.y); o.z = roottanh_f(o.z); o.w = roottanh_f(o.w); }
+            o4[i] = o;
         }
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t p = i / hw;
+        const int64_t p = plane0 + i / hw;
         const int c = (int)(p % C);
         const float y = scale[scale_per_sample ? p : c];
         const float o = (x[i] - mu) * y / s + bias[c];
-        if (ACT) act[i] = roottanh_f(o);
-        else out[i] = o;
+        out[i] = ACT ? roottanh_f(o) : o;
     }
 }
 
 // out = (x - mean(x)) * scale / std(x) + bias  (with_act = 0), or RootTanh of it (with_act = 1; the plain value is not
-// stored - backward recomputes it).  stats_out receives {mean, std}.  Two launches.
+// stored - backward recomputes it).  B = groups * (B / groups); statistics per group; stats_out: [groups][2].
+// scale: [C] (scale_per_sample = 0) or [B*C].  Two launches.
 LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out,
-                               int with_act, float* stats_out, int B, int C, int hw, void* workspace, void* stream) {
+                               int with_act, float* stats_out, int B, int C, int hw, int groups, void* workspace,
+                               void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace && stats_out && out, "locate_norm_fwd: bad arguments");
+    LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_fwd: bad group count %d for batch %d", groups, B);
     LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_fwd: x must be 16-byte aligned");
-    const int64_t planes = (int64_t)B * C, n = planes * hw;
-    LOCATE_REQUIRE(n > 1, "locate_norm_fwd: needs at least two elements");
-    int np = stream_grid(n, 256 * 16);
+    const int64_t planes_g = (int64_t)(B / groups) * C, n_g = planes_g * hw;
+    LOCATE_REQUIRE(n_g > 1, "locate_norm_fwd: needs at least two elements per group");
+    LOCATE_REQUIRE(groups == 1 || (n_g & 3) == 0, "locate_norm_fwd: grouped tensors need a group size that is a multiple of 4");
+    int np = stream_grid(n_g, 256 * 16);
     if (np > NORM_MAX_PARTIALS) np = NORM_MAX_PARTIALS;
     double* partial = static_cast<double*>(workspace);
-    stats_partial_kernel<<<np, 256, 0, as_stream(stream)>>>(x, n, partial);
+    hipStream_t st = as_stream(stream);
+    stats_partial_kernel<<<dim3(np, groups), 256, 0, st>>>(x, n_g, partial);
     LOCATE_LAUNCH_CHECK("locate_norm_fwd(stats)");
-    const int grid = stream_grid(n, 1024);
+    const dim3 grid(stream_grid(n_g, 1024), groups);
     if (with_act)
-        norm_apply_fused_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(x, partial, np, stats_out, scale, scale_per_sample, bias,
-                                                                          nullptr, out, planes, C, hw);
+        norm_apply_fused_kernel<true><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw);
     else
-        norm_apply_fused_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(x, partial, np, stats_out, scale, scale_per_sample,
-                                                                           bias, out, nullptr, planes, C, hw);
+        norm_apply_fused_kernel<false><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_fwd(apply)");
     return LOCATE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward
-//   pass 1 (one wave per plane):   S1[p] = sum g,  S2[p] = sum (x - mu) g
-//   pass 2 (one block):            dbias[c], dscale, consts = { mean(y g / s), dz / ((N-1) s) }
-//   pass 3 (element-wise):         dx = y[p] g / s - consts[0] + consts[1] (x - mu)
+//   pass 1 (one wave per plane):   S1[p] = sum go,  S2[p] = sum (x - mu_g) go      (go = g, or g * RootTanh'(out) with ACT)
+//   pass 2 (one block):            dbias[c], dscale, consts[g] = { mean(y go / s_g), dz_g / ((N_g - 1) s_g) }
+//   pass 3 (element-wise):         dx = y[p] go / s_g - consts[g][0] + consts[g][1] (x - mu_g)
 // ---------------------------------------------------------------------------------------------
-// ACT: g is the gradient w.r.t. RootTanh(out); go = g * RootTanh'(out) with out = (x - mu) * y / s + b recomputed
 template <bool ACT>
 __device__ __forceinline__ float norm_go(float xv, float gv, float mu, float s, float y, float b) {
     if (!ACT) return gv;
@@ -244,12 +186,13 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
                                                              const float* __restrict__ stats, const float* __restrict__ scale,
                                                              int scale_per_sample, const float* __restrict__ bias, int C,
                                                              float* __restrict__ S1, float* __restrict__ S2, int64_t planes,
-                                                             int hw) {
-    const float mu = stats[0], sd = stats[1];
+                                                             int64_t planes_g, int hw) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t p = wave; p < planes; p += nwaves) {
+        const int grp = (int)(p / planes_g);
+        const float mu = stats[2 * grp], sd = stats[2 * grp + 1];
         const int64_t base = p * hw;
         const int c = (int)(p % C);
         const float y = ACT ? scale[scale_per_sample ? p : c] : 0.0f, b = ACT ? bias[c] : 0.0f;
@@ -283,53 +226,64 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
 }
 
 // One block, deterministic (fixed summation order - no atomics - so that eager and hipGraph replays agree bit for
-// bit): thread (c, grp) sums its share of the batch for channel c, the groups meet through LDS in a fixed order.
+// bit): thread (c, slot) sums its share of the batch for channel c, the slots meet through LDS in a fixed order.
 __global__ void __launch_bounds__(1024) norm_bwd_final_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
                                                               const float* __restrict__ stats, const float* __restrict__ scale,
                                                               int scale_per_sample, float* __restrict__ dscale,
                                                               float* __restrict__ dbias, float* __restrict__ consts, int B,
-                                                              int C, int hw) {
+                                                              int C, int hw, int groups) {
     __shared__ double scratch[16];
     __shared__ float part_b[1024], part_y[1024];
-    const double s = (double)stats[1];
-    const float sf = stats[1];
-    const int64_t planes = (int64_t)B * C;
-    const double n = (double)planes * (double)hw;
-    double sum_yg = 0.0, sum_yxg = 0.0;
+    const int Bg = B / groups;
+    double sum_yg[NORM_MAX_GROUPS], sum_yxg[NORM_MAX_GROUPS];
+#pragma unroll
+    for (int g = 0; g < NORM_MAX_GROUPS; ++g) sum_yg[g] = sum_yxg[g] = 0.0;
     for (int c0 = 0; c0 < C; c0 += 1024) {                 // channel tiles of up to 1024 (one pass for every shipped width)
         const int cw = min(1024, C - c0);
-        const int groups = max(1, 1024 / cw);
-        const int cl = threadIdx.x % cw, grp = threadIdx.x / cw;
+        const int slots = max(1, 1024 / cw);
+        const int cl = threadIdx.x % cw, slot = threadIdx.x / cw;
         float db = 0.0f, dy = 0.0f;
-        if (grp < groups) {
+        if (slot < slots) {
             const int c = c0 + cl;
-            for (int b = grp; b < B; b += groups) {
+            for (int b = slot; b < B; b += slots) {
+                const int grp = b / Bg;
+                const float sf = stats[2 * grp + 1];
                 const int64_t p = (int64_t)b * C + c;
                 const float s1 = S1[p], s2 = S2[p];
                 const float y = scale[scale_per_sample ? p : c];
                 db += s1;
                 if (scale_per_sample) dscale[p] = s2 / sf;
-                else dy += s2;
-                sum_yg += (double)y * (double)s1;
-                sum_yxg += (double)y * (double)s2;
+                else dy += s2 / sf;
+#pragma unroll
+                for (int g = 0; g < NORM_MAX_GROUPS; ++g)
+                    if (g == grp) {
+                        sum_yg[g] += (double)y * (double)s1;
+                        sum_yxg[g] += (double)y * (double)s2;
+                    }
             }
         }
         __syncthreads();
-        if (grp < groups) { part_b[grp * cw + cl] = db; part_y[grp * cw + cl] = dy; }
+        if (slot < slots) { part_b[slot * cw + cl] = db; part_y[slot * cw + cl] = dy; }
         __syncthreads();
         if ((int)threadIdx.x < cw) {
             float tb = 0.0f, ty = 0.0f;
-            for (int g2 = 0; g2 < groups; ++g2) { tb += part_b[g2 * cw + threadIdx.x]; ty += part_y[g2 * cw + threadIdx.x]; }
+            for (int g2 = 0; g2 < slots; ++g2) { tb += part_b[g2 * cw + threadIdx.x]; ty += part_y[g2 * cw + threadIdx.x]; }
             dbias[c0 + threadIdx.x] = tb;
-            if (!scale_per_sample) dscale[c0 + threadIdx.x] = ty / sf;
+            if (!scale_per_sample) dscale[c0 + threadIdx.x] = ty;
         }
     }
-    sum_yg = block_sum<double>(sum_yg, scratch);
-    sum_yxg = block_sum<double>(sum_yxg, scratch);
-    if (threadIdx.x == 0) {
-        const double dz = -sum_yxg / (s * s);
-        consts[0] = (float)(sum_yg / s / n);
-        consts[1] = (float)(dz / ((n - 1.0) * s));
+    const double n = (double)Bg * (double)C * (double)hw;     // elements per group
+#pragma unroll
+    for (int g = 0; g < NORM_MAX_GROUPS; ++g) {
+        if (g >= groups) break;
+        const double a = block_sum<double>(sum_yg[g], scratch);
+        const double b2 = block_sum<double>(sum_yxg[g], scratch);
+        if (threadIdx.x == 0) {
+            const double s = (double)stats[2 * g + 1];
+            const double dz = -b2 / (s * s);
+            consts[2 * g] = (float)(a / s / n);
+            consts[2 * g + 1] = (float)(dz / ((n - 1.0) * s));
+        }
     }
 }
 
@@ -338,10 +292,13 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
                                                           const float* __restrict__ stats, const float* __restrict__ scale,
                                                           int scale_per_sample, const float* __restrict__ bias,
                                                           const float* __restrict__ consts, float* __restrict__ dx,
-                                                          int64_t planes, int C, int hw) {
-    const float mu = stats[0], s = stats[1];
-    const float m = consts[0], k = consts[1];
-    const int64_t n = planes * hw;
+                                                          int64_t planes_g, int C, int hw) {
+    const int grp = blockIdx.y;
+    const float mu = stats[2 * grp], s = stats[2 * grp + 1];
+    const float m = consts[2 * grp], k = consts[2 * grp + 1];
+    const int64_t n = planes_g * hw;
+    x += (int64_t)grp * n; g += (int64_t)grp * n; dx += (int64_t)grp * n;
+    const int64_t plane0 = (int64_t)grp * planes_g;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if ((hw & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -349,7 +306,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         float4* o4 = reinterpret_cast<float4*>(dx);
         const int hw4 = hw >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
-            const int64_t p = i / hw4;
+            const int64_t p = plane0 + i / hw4;
             const int c = (int)(p % C);
             const float y = scale[scale_per_sample ? p : c], b = ACT ? bias[c] : 0.0f;
             const float4 xv = x4[i];
@@ -364,7 +321,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t p = i / hw;
+        const int64_t p = plane0 + i / hw;
         const int c = (int)(p % C);
         const float y = scale[scale_per_sample ? p : c];
         const float gv = norm_go<ACT>(x[i], g[i], mu, s, y, ACT ? bias[c] : 0.0f);
@@ -373,19 +330,21 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
 }
 
 LOCATE_API size_t locate_norm_bwd_workspace_bytes(int B, int C) {
-    return ((size_t)B * C * 2 + 4) * sizeof(float);
+    return ((size_t)B * C * 2 + 2 * NORM_MAX_GROUPS + 4) * sizeof(float);
 }
 
-// dscale: [C] (scale_per_sample = 0) or [B*C];  dbias: [C].  Both overwritten.
+// dscale: [C] (scale_per_sample = 0) or [B*C];  dbias: [C].  Both overwritten.  stats: [groups][2] from the forward.
 // with_act = 1: g is the gradient w.r.t. RootTanh(norm(x)) (the fused forward of locate_norm_fwd); the activation's
 // derivative is applied on the fly from the recomputed norm output, so neither that output nor a separate
 // RootTanh-backward pass exists.
 LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale,
                                int scale_per_sample, const float* bias, int with_act, float* dx, float* dscale, float* dbias,
-                               int B, int C, int hw, void* workspace, void* stream) {
+                               int B, int C, int hw, int groups, void* workspace, void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd: bad shape or missing workspace");
+    LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_bwd: bad group count");
     LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd: with_act needs the bias");
-    const int64_t planes = (int64_t)B * C;
+    const int64_t planes = (int64_t)B * C, planes_g = planes / groups;
+    LOCATE_REQUIRE(groups == 1 || ((planes_g * hw) & 3) == 0, "locate_norm_bwd: grouped tensors need a group size that is a multiple of 4");
     float* S1 = static_cast<float*>(workspace);
     float* S2 = S1 + planes;
     float* consts = S2 + planes;
@@ -393,17 +352,17 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = as_stream(stream);
     if (with_act)
-        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, hw);
+        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw);
     else
-        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, hw);
+        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(plane)");
-    norm_bwd_final_kernel<<<1, 1024, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts, B, C, hw);
+    norm_bwd_final_kernel<<<1, 1024, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts, B, C, hw, groups);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
-    const int grid = stream_grid(planes * hw, 1024);
+    const dim3 grid(stream_grid(planes_g * hw, 1024), groups);
     if (with_act)
-        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes, C, hw);
+        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes_g, C, hw);
     else
-        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes, C, hw);
+        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes_g, C, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
     return LOCATE_OK;
 }

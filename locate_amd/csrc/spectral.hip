@@ -195,6 +195,91 @@ __global__ void __launch_bounds__(256) sn_rank1_kernel(const double* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stacked forwards ("groups" along the batch, each with its own sigma_k): <G_k, W_bar> is taken on the activation
+// side, <G_k, W_bar> = <gy_k, conv(x_k, W_bar)> = sigma_k <gy_k, y_k - bias>, so
+//     dsigma_k = -<G_k, W_bar> / sigma_k^2 = -(1 / sigma_k) * sum_{b in k, m, p} gy[b,m,p] (y[b,m,p] - bias[m])
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sn_group_dot_kernel(const float* __restrict__ gy, int64_t gy_bs, const float* __restrict__ y,
+                                                           int64_t y_bs, const float* __restrict__ bias, int Bg, int M, int plane,
+                                                           double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    const int grp = blockIdx.y;
+    const int64_t per_b = (int64_t)M * plane, total = (int64_t)Bg * per_b;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t bl = i / per_b, r = i - bl * per_b;
+        const int64_t b = (int64_t)grp * Bg + bl;
+        const float yv = y[b * y_bs + r] - (bias ? bias[(int)(r / plane)] : 0.0f);
+        acc += (double)gy[b * gy_bs + r] * (double)yv;
+    }
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) partial[(int64_t)grp * gridDim.x + blockIdx.x] = acc;
+}
+
+// gw += (sum_k dsigma_k) u v^T;  block 0: du = sum_k dsigma_k wv_k, dsigma_total_out = sum_k dsigma_k
+__global__ void __launch_bounds__(256) sn_rank1_grouped_kernel(const double* __restrict__ partial, int npartial, int groups,
+                                                               const float* __restrict__ sigma_tab, int sigma_stride,
+                                                               const float* __restrict__ u, const float* __restrict__ v,
+                                                               const float* __restrict__ wv, int64_t wv_stride,
+                                                               float* __restrict__ gw, float* __restrict__ du,
+                                                               float* __restrict__ dsigma_total_out, int h, int wd) {
+    __shared__ double scratch[16];
+    float dsg[4] = {0.f, 0.f, 0.f, 0.f};
+    float total = 0.0f;
+    for (int k = 0; k < groups; ++k) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[(int64_t)k * npartial + i];
+        acc = block_sum<double>(acc, scratch);
+        dsg[k] = (float)(-acc * (double)sigma_tab[k * sigma_stride + 1]);     // [k][1] = 1 / sigma_k
+        total += dsg[k];
+    }
+    const int64_t n = (int64_t)h * wd;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
+        gw[i] = fmaf(total * u[r], v[c], gw[i]);
+    }
+    if (blockIdx.x == 0) {
+        if (du)
+            for (int i = threadIdx.x; i < h; i += blockDim.x) {
+                float a = 0.0f;
+                for (int k = 0; k < groups; ++k) a = fmaf(dsg[k], wv[(int64_t)k * wv_stride + i], a);
+                du[i] = a;
+            }
+        if (threadIdx.x == 0 && dsigma_total_out) dsigma_total_out[0] = total;
+    }
+}
+
+LOCATE_API size_t locate_sn_group_workspace_bytes(void) { return 4 * 256 * sizeof(double); }
+
+// Spectral-norm backward for `groups` (<= 4) forwards stacked along the batch of one layer call.
+//   gw (in/out): sum_k G_k / sigma_k (from locate_conv_wgrad with group scaling) -> dW_bar (rank-1 correction added)
+//   gy / y: gradient and output of the layer call [groups*Bg, M, plane] (batch strides in elements), bias nullable
+//   sigma_tab: {sigma_k, 1/sigma_k} pairs sigma_stride floats apart; wv: W v_k rows wv_stride floats apart
+//   du (nullable) = sum_k dsigma_k W v_k;  dsigma_total_out (nullable) = sum_k dsigma_k
+LOCATE_API int locate_sn_weight_bwd_grouped(const float* gy, int64_t gy_bs, const float* y, int64_t y_bs, const float* bias,
+                                            int groups, int Bg, int M, int plane, const float* sigma_tab, int sigma_stride,
+                                            const float* u, const float* v, const float* wv, int64_t wv_stride, float* gw,
+                                            float* du, float* dsigma_total_out, int h, int wd, void* workspace, void* stream) {
+    LOCATE_REQUIRE(gy && y && sigma_tab && u && v && gw && workspace && groups >= 1 && groups <= 4 && Bg > 0 && M > 0 && plane > 0,
+                   "locate_sn_weight_bwd_grouped: bad arguments");
+    LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd_grouped: du requested without the saved W v");
+    hipStream_t st = as_stream(stream);
+    double* partial = static_cast<double*>(workspace);
+    const int64_t total = (int64_t)Bg * M * plane;
+    int nb = stream_grid(total, 1024);
+    if (nb > 256) nb = 256;
+    sn_group_dot_kernel<<<dim3(nb, groups), 256, 0, st>>>(gy, gy_bs, y, y_bs, bias, Bg, M, plane, partial);
+    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd_grouped(dot)");
+    const int64_t n = (int64_t)h * wd;
+    sn_rank1_grouped_kernel<<<stream_grid(n, 1024), 256, 0, st>>>(partial, nb, groups, sigma_tab, sigma_stride, u, v, wv, wv_stride,
+                                                                 gw, du, dsigma_total_out, h, wd);
+    LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd_grouped(rank1)");
+    return LOCATE_OK;
+}
+
 // dv[col] = (sum of the layer's dsigma slots) * t[col];  the slots are cleared for the next backward pass
 __global__ void __launch_bounds__(SN_COLS) sn_dv_batched_kernel(const SnLayer* __restrict__ table) {
     const SnLayer L = table[blockIdx.y];

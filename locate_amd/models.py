@@ -97,10 +97,12 @@ class SpectralNormBatch:
         return sig, wvs
 
     def assign(self, sig, wvs):
-        """Hand one power iteration's results to the layers (consumed by their next forward)."""
+        """Hand one power iteration's results to the layers (consumed by their next forward).  sig [n, 2], wvs [H]; or,
+        for a forward over k stacked calls, sig [n, k, 2], wvs [k, H] (one iteration per call, in call order)."""
         hoff = 0
+        stacked = sig.dim() == 3
         for i, (sn, (h, _, _)) in enumerate(zip(self.layers, self._meta)):
-            sn._pre = (sig[i], wvs[hoff:hoff + h])
+            sn._pre = (sig[i], wvs[:, hoff:hoff + h] if stacked else wvs[hoff:hoff + h])
             hoff += h
 
 
@@ -123,12 +125,18 @@ class _NetBase(nn.Module):
             if sig is not None:
                 self._sn_queue.append((sig, wvs))
 
-    def _sn_prologue(self):
+    def _sn_prologue(self, stacked=1):
+        if stacked > 1 and not self.batched_spectral_norm:
+            raise RuntimeError("a forward over stacked calls needs batched_spectral_norm = True")
         if self.batched_spectral_norm:
             b = self._batch()
-            sig, wvs = self._sn_queue.pop(0) if self._sn_queue else b.run()
-            if sig is not None:
-                b.assign(sig, wvs)
+            runs = [self._sn_queue.pop(0) if self._sn_queue else b.run() for _ in range(stacked)]
+            if runs[0][0] is None:
+                return
+            if stacked == 1:
+                b.assign(*runs[0])
+            else:
+                b.assign(torch.stack([r[0] for r in runs], dim=1), torch.stack([r[1] for r in runs], dim=0))
 
 
 class Generator(_NetBase):
@@ -171,9 +179,15 @@ class Discriminator(_NetBase):
         head = DeepResidualConv(block_block.out_features, 1, False, 1, False, 2, 1, cfg=cfg)   # END_LAYER = 1
         self.main = nn.Sequential(stem, block_block, head)
 
-    def forward(self, function_input):
-        self._sn_prologue()
-        return self.main(function_input)
+    def forward(self, function_input, stacked=1):
+        """stacked = k > 1: `function_input` stacks k independent calls along the batch (k equal slices); the result
+        equals running them one after the other (k power iterations in order, per-call InPlaceNorm statistics), in
+        one pass over the network - the three D passes of the reference's D-step (main.py:149-152)."""
+        self._sn_prologue(stacked)
+        if stacked == 1:
+            return self.main(function_input)
+        with ops.stacked_calls(stacked):
+            return self.main(function_input)
 
 
 def init(module):

@@ -84,6 +84,24 @@ tanh = TanhFn.apply
 # ------------------------------------------------------------------------------------------------
 # InPlaceNorm
 # ------------------------------------------------------------------------------------------------
+class stacked_calls:
+    """Context: the batch of every op inside stacks `n` independent forward calls of the network (the reference runs
+    them one after the other, main.py:149-152).  Ops whose result depends on the whole batch - InPlaceNorm's global
+    statistics - then treat each of the n equal slices on its own."""
+    current = 1
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = stacked_calls.current
+        stacked_calls.current = self.n
+
+    def __exit__(self, *exc):
+        stacked_calls.current = self.prev
+        return False
+
+
 class InPlaceNormFn(torch.autograd.Function):
     """out = (x - mean(x)) * scale / std(x) + bias with global scalar statistics.  With `with_act` the forward
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
@@ -93,18 +111,21 @@ class InPlaceNormFn(torch.autograd.Function):
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
+        groups = stacked_calls.current
+        if B % groups:
+            raise ValueError("norm: batch %d does not split into %d stacked calls" % (B, groups))
         per_sample = scale.numel() == B * C and (B > 1 and scale.shape[0] == B)
         if not per_sample and scale.numel() != C:
             raise ValueError("norm scale must have C or B*C elements, got %s for input %s" % (tuple(scale.shape), tuple(x.shape)))
         scale_c, bias_c = _c(scale, "norm scale"), _c(bias, "norm bias")
         L = lib()
         st = _stream()
-        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        stats = torch.empty(2 * groups, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device)
         out = torch.empty_like(x)       # RootTanh(norm(x)) when with_act, else norm(x)
         check(L.locate_norm_fwd(_p(x), _p(scale_c), int(per_sample), _p(bias_c), _p(out), int(bool(with_act)), _p(stats), B, C, hw,
-                                _p(ws), st), "locate_norm_fwd")
-        ctx.per_sample, ctx.with_act = per_sample, bool(with_act)
+                                groups, _p(ws), st), "locate_norm_fwd")
+        ctx.per_sample, ctx.with_act, ctx.groups = per_sample, bool(with_act), groups
         ctx.scale_shape, ctx.bias_shape = scale.shape, bias.shape
         ctx.save_for_backward(x, scale_c, bias_c, stats)
         return out
@@ -122,7 +143,7 @@ class InPlaceNormFn(torch.autograd.Function):
         dbias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
-                                _p(dscale), _p(dbias), B, C, hw, _p(ws), st), "locate_norm_bwd")
+                                _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), st), "locate_norm_bwd")
         return dx, dscale, dbias, None
 
 
@@ -489,17 +510,27 @@ class SNConvFn(torch.autograd.Function):
         geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
         garr = _geom(geom)
         y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-        inv_sigma = sigma[1:]
+        # sigma: {sigma, 1/sigma}, or [n, 2] for n stacked calls (one power iteration each, in call order)
+        groups = sigma.shape[0] if sigma.dim() == 2 else 1
+        if groups > 1 and (x.shape[0] % groups or groups > 4 or sigma.stride(1) != 1):
+            raise ValueError("conv: batch %d cannot stack %d calls" % (x.shape[0], groups))
+        sbg = x.shape[0] // groups if groups > 1 else 0
+        sst = sigma.stride(0) if groups > 1 else 0
+        inv_sigma = sigma.reshape(-1)[1:] if groups == 1 else sigma[0, 1:]
         b = _c(bias) if bias is not None else None
         if spec.kind == "conv":
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), _p(b), _p(y), _bs(y), _p(ws),
-                                    st), "locate_conv_fwd")
+            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(b), _p(y),
+                                    _bs(y), _p(ws), st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), _p(b), _p(y), _bs(y),
-                                      _p(ws), st), "locate_conv_dgrad")
-        ctx.save_for_backward(x, w, sigma, wv)
+            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(b), _p(y),
+                                      _bs(y), _p(ws), st), "locate_conv_dgrad")
+        ctx.groups = groups
+        if groups > 1:
+            ctx.save_for_backward(x, w, sigma, wv, y, b)     # <G_k, W_bar> is taken on the activation side (needs y)
+        else:
+            ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.owner = owner
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
@@ -509,25 +540,52 @@ class SNConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         L = lib()
         st = _stream()
-        x, w, sigma, wv = ctx.saved_tensors
+        groups = ctx.groups
+        if groups > 1:
+            x, w, sigma, wv, y, bsaved = ctx.saved_tensors
+        else:
+            x, w, sigma, wv = ctx.saved_tensors
         spec, garr = ctx.spec, _geom(ctx.geom)
         _chk(gy, "conv output gradient")
         if not _dense_planes(gy):
             gy = gy.contiguous()
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
         gx = gw = gu = gv = gb = None
-        inv_sigma = sigma[1:]
+        sbg = x.shape[0] // groups if groups > 1 else 0
+        sst = sigma.stride(0) if groups > 1 else 0
+        inv_sigma = sigma.reshape(-1)[1:] if groups == 1 else sigma[0, 1:]
         if need_x:
             gx = torch.empty_like(x)
             if spec.kind == "conv":
                 ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 1)), _p(inv_sigma), None, _p(gx),
-                                          _bs(gx), _p(ws), st), "locate_conv_dgrad")
+                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 1)), _p(inv_sigma), sbg, sst,
+                                          None, _p(gx), _bs(gx), _p(ws), st), "locate_conv_dgrad")
             else:
                 ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 0)), _p(inv_sigma), None, _p(gx),
-                                        _bs(gx), _p(ws), st), "locate_conv_fwd")
-        if need_w or need_u or need_v:
+                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 0)), _p(inv_sigma), sbg, sst,
+                                        None, _p(gx), _bs(gx), _p(ws), st), "locate_conv_fwd")
+        if groups > 1 and (need_w or need_u or need_v):
+            # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
+            # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
+            gw = torch.empty_like(w)
+            ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
+            xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)
+            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), None, _p(inv_sigma), sbg, sst, None,
+                                      _p(ws), st), "locate_conv_wgrad")
+            h = w.shape[0]
+            wd = w.numel() // h
+            u, v = ctx.u.detach(), ctx.v.detach()
+            gu = torch.empty_like(u) if need_u else None
+            dsig = _register_pending_dv(ctx.v, ctx.u, w, h, wd) if need_v else None
+            gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
+            Bn, Mn = gy.shape[0], gy.shape[1]
+            check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bsaved), groups, Bn // groups, Mn,
+                                                 gy.numel() // (Bn * Mn), _p(sigma), sigma.stride(0), _p(u), _p(v), _p(wv),
+                                                 wv.stride(0), _p(gw), _p(gu), _p(dsig), h, wd, _p(gws), st),
+                  "locate_sn_weight_bwd_grouped")
+            if not need_w:
+                gw = None
+        elif need_w or need_u or need_v:
             # one pass: gw = G / sigma_k (G = gradient w.r.t. the normalised weight) plus the partial sums of <G, W_bar>;
             # then the rank-1 spectral-norm correction in place
             gw = torch.empty_like(w)
@@ -535,7 +593,7 @@ class SNConvFn(torch.autograd.Function):
             partial = torch.empty(npart, dtype=torch.float64, device=x.device)
             ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
             xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
-            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), _p(partial),
+            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), 0, 0, _p(partial),
                                       _p(ws), st), "locate_conv_wgrad")
             h = w.shape[0]
             wd = w.numel() // h

@@ -21,7 +21,8 @@ def _stream():
 
 
 def d_loss(d_true, d_fake, d_aug, gamma=100.0):
-    """Returns (losses[3] = {d_error, penalty, total}, g_true, g_fake, g_aug)."""
+    """Returns (losses[3] = {d_error, penalty, total}, g_true, g_fake, g_aug); the three gradients are the rows of one
+    [3, B] tensor (g_true._base)."""
     B = d_true.numel()
     dev = d_true.device
     losses = torch.empty(3, dtype=torch.float32, device=dev)
@@ -43,8 +44,14 @@ def g_loss(d_fake):
 
 class TrainStep:
     def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None,
-                 concurrent_d=False):
+                 concurrent_d=False, stacked_d=None):
         self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
+        # stacked_d: the D-step's three discriminator passes (real / fake / augmented) run as ONE pass over a [3B] batch
+        # with per-call InPlaceNorm statistics and per-call spectral-norm sigma (three power iterations up front, in the
+        # reference's order) - same values, a third of the launches, no cross-graph gradient accumulation.
+        # Default: on whenever the discriminator uses the batched spectral norm.
+        self.stacked_d = (bool(getattr(dis, "batched_spectral_norm", False)) and not concurrent_d) if stacked_d is None \
+            else bool(stacked_d)
         self.penalty_gamma = penalty_gamma
         self.minibatches = minibatches
         self.reducer_g, self.reducer_d = reducer_g, reducer_d
@@ -88,6 +95,20 @@ class TrainStep:
     def d_forward_backward(self, latent, real, aug):
         gen, dis = self.gen, self.dis
         dis.zero_grad()                            # main.py:148
+        if self.stacked_d and getattr(dis, "batched_spectral_norm", False):
+            with torch.no_grad():
+                generated = gen(latent)
+            B = real.shape[0]
+            d_all = dis(torch.cat([real, generated, aug], dim=0), stacked=3)   # :149, :150, grad_penalty.py:2 in one pass
+            d_true, d_fake, d_aug = d_all[:B], d_all[B:2 * B], d_all[2 * B:]
+            losses, g_t, _, _ = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
+            if self.reducer_d is not None:
+                self.reducer_d.begin()
+            d_all.backward(g_t._base.view_as(d_all))                           # :156
+            if self.reducer_d is not None:
+                self.reducer_d.finish()
+            return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
+                    "d_gen": -d_fake.detach().view(-1), "generated": generated}
         if self.concurrent_d:
             generated, d_true, d_fake, d_aug = self._d_forwards_concurrent(latent, real, aug)
         else:

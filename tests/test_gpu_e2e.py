@@ -33,7 +33,7 @@ def assert_step_close(got, want, lr, step, what):
     assert float(d.max()) <= 2.5 * lr, "%s: max |delta| = %.3e lr" % (what, float(d.max()) / lr)
 
 
-def _build_tiny(z, batched_sn=False, concurrent_d=False):
+def _build_tiny(z, batched_sn=False, concurrent_d=False, stacked_d=False):
     from locate_amd import Discriminator, Generator, Nadam, NetConfig, TrainStep
     cfg = NetConfig(image_size=32, base_feature_factor=1)
     G, D = Generator(cfg), Discriminator(cfg)
@@ -44,14 +44,19 @@ def _build_tiny(z, batched_sn=False, concurrent_d=False):
     G, D = G.to(dev), D.to(dev)
     G.batched_spectral_norm = D.batched_spectral_norm = batched_sn
     step = TrainStep(G, D, Nadam(G.parameters(), lr=cfg.glr, betas=(cfg.beta1, cfg.beta2)),
-                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), concurrent_d=concurrent_d)
+                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), concurrent_d=concurrent_d,
+                     stacked_d=stacked_d)
     return cfg, G, D, step, dev
 
 
-@pytest.mark.parametrize("batched_sn,concurrent_d", [(False, False), (True, False), (True, True)])
-def test_tiny_two_steps_golden(batched_sn, concurrent_d):
+@pytest.mark.parametrize("batched_sn,concurrent_d,stacked_d", [(False, False, False), (True, False, False), (True, True, False),
+                                                                (True, False, True)])
+def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d):
+    """Two full iterations against the reference's record, in every launch mode: per-layer spectral norm, batched
+    spectral norm, three-stream D-step, and the D-step's three passes stacked into one [3B] pass."""
     z = load_golden("g8_tiny_e2e")
-    cfg, G, D, step, dev = _build_tiny(z, batched_sn, concurrent_d)
+    cfg, G, D, step, dev = _build_tiny(z, batched_sn, concurrent_d, stacked_d)
+    assert step.stacked_d == stacked_d
     for it in (1, 2):
         p = "step%d/" % it
         # capture gradients and pre-step u/v through hooks on the optimizers' step
@@ -152,8 +157,8 @@ def test_graph_replay_equals_eager():
     """hipGraph replay of the four captured phases must produce the same trajectory as eager launches."""
     from locate_amd.graph import GraphedTrainStep
     z = load_golden("g8_tiny_e2e")
-    cfg, G1, D1, step1, dev = _build_tiny(z, True)
-    _, G2, D2, step2, _ = _build_tiny(z, True, concurrent_d=True)      # graphs capture the three-stream D-step
+    cfg, G1, D1, step1, dev = _build_tiny(z, True, stacked_d=True)    # same arithmetic, launched eagerly
+    _, G2, D2, step2, _ = _build_tiny(z, True, stacked_d=True)         # graphs capture the stacked D-step (bench mode)
     lat, real, aug = (T(z["step1/" + k]).to(dev) for k in ("latent", "real", "aug"))
     runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations, then capture (no execution)
     for _ in range(2):

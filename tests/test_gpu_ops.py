@@ -225,6 +225,33 @@ def test_batched_spectral_norm_equals_per_layer():
             assert_close(b.grad.cpu(), a.grad.cpu(), 1e-5, k)
 
 
+@pytest.mark.parametrize("size,ff,B", [(32, 1, 4), (32, 4, 2), (64, 1, 2)])
+def test_stacked_discriminator_pass_equals_three_calls(size, ff, B):
+    """D over a [3B] batch with stacked=3 == three D calls in order (outputs, u/v state, all gradients incl. u/v)."""
+    from locate_amd import Discriminator, NetConfig
+    cfg = NetConfig(image_size=size, base_feature_factor=ff)
+    torch.manual_seed(11)
+    D1 = Discriminator(cfg).to(dev())
+    D2 = Discriminator(cfg).to(dev())
+    D2.load_state_dict(D1.state_dict())
+    D1.batched_spectral_norm = D2.batched_spectral_norm = True
+    D1.requires_grad_(True)          # u, v trainable like after the reference's main.py:172
+    D2.requires_grad_(True)
+    xs = [torch.randn(B, 3, size, size, device=dev()) * (1 + k) for k in range(3)]     # different statistics per call
+    gs = [torch.randn(B, 1, 1, 1, device=dev()) for _ in range(3)]
+    ys = [D1(x) for x in xs]
+    torch.autograd.backward(ys, [g.view_as(y) for g, y in zip(gs, ys)])
+    y_all = D2(torch.cat(xs), stacked=3)
+    y_all.backward(torch.cat(gs).view_as(y_all))
+    assert_close(y_all.detach().cpu(), torch.cat(ys).detach().cpu(), 2e-5, "outputs")
+    for (k, a), (_, b) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert_close(b.cpu(), a.cpu(), 1e-6, k)
+    for (k, a), (_, b) in zip(D1.named_parameters(), D2.named_parameters()):
+        assert (a.grad is None) == (b.grad is None), k
+        if a.grad is not None:
+            assert_close(b.grad.cpu(), a.grad.cpu(), 2e-4, "grad " + k)
+
+
 # ---------------------------------------------------------------------- dense contractions vs torch CPU
 CONV_CASES = [
     # kind, Cin, Cout, k, stride, pad, B, H, W

@@ -78,21 +78,21 @@ def main():
         ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
 
         def r_fwd(inp, out):      # R forward
-            check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), None, out.data_ptr(),
+            check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
                                     out.stride(0), ws_f.data_ptr(), st))
 
         def r_dgrad(inp, out):    # R data adjoint
-            check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), None, out.data_ptr(),
+            check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
                                       out.stride(0), ws_d.data_ptr(), st))
 
         if kind == "conv":
             fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), part.data_ptr(), ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), st))
         else:
             fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), part.data_ptr(), ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), st))
         OH = out_shape[2]
         if kind == "conv":
             flops = 2.0 * B * OH * OH * cout * cin * k * k
