@@ -118,6 +118,81 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackBatch batch
     }
 }
 
+__device__ __forceinline__ void pack_tables(const PackArgs& a, int k) {
+    int* koff = reinterpret_cast<int*>(a.out + (size_t)a.rows * a.ld);
+    unsigned char* ktap = reinterpret_cast<unsigned char*>(koff + a.rows);
+    const int T = a.TH * a.TW;
+    int off = 0, tap = 31;
+    if (k < a.K && T > 0) {
+        const int c = k / T, t = k - c * T;
+        const int th = t / a.TW, tw = t - th * a.TW;
+        off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
+        tap = t;
+    }
+    koff[k] = off;
+    ktap[k] = (unsigned char)tap;
+}
+
+// mode 0 (R forward): the panel is the transpose of W viewed as [M][K]: 64 x 64 tiles through LDS, both the read
+// (along k) and the write (along m) are coalesced.  grid (rows / 64, ld / 64).
+__global__ void __launch_bounds__(256) pack_transpose_kernel(const PackArgs a) {
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        const int m = m0 + j, k = k0 + tx;
+        tile[j][tx] = (m < a.M && k < a.K) ? a.w[(int64_t)m * a.K + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int k = k0 + j, m = m0 + tx;
+        if (k < a.rows && m < a.ld) a.out[(int64_t)k * a.ld + m] = tile[tx][j];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 64 && k0 + (int)threadIdx.x < a.rows) pack_tables(a, k0 + threadIdx.x);
+}
+
+// mode 1 (data adjoint, all sub-pixel phases at once): for one m, W[m] is a [C][KH*KW] matrix; a block stages 256
+// channels of it in LDS (contiguous read) and writes, per tap, one 256-wide piece of the row (m, tap) of the phase
+// that owns the tap.  blockIdx.y == M: zero tail rows and the offset tables.  grid (ld / 256, M + 1).
+#define PACK_MAX_TAPS 32
+__global__ void __launch_bounds__(256) pack_adjoint_kernel(const PackBatch batch, int nphase) {
+    __shared__ float lds[256 * (PACK_MAX_TAPS + 1)];
+    const PackArgs& a0 = batch.ph[0];
+    const int KK = a0.KH * a0.KW, S = KK | 1;
+    const int m = blockIdx.y, c0 = blockIdx.x * 256;
+    const int col = c0 + threadIdx.x;
+    if (m < a0.M) {
+        const int cn = min(256, a0.C - c0);
+        if (cn > 0) {
+            const float* src = a0.w + ((int64_t)m * a0.C + c0) * KK;
+            const int total = cn * KK;
+            for (int idx = threadIdx.x; idx < total; idx += 256) {
+                const int cl = idx / KK, t = idx - cl * KK;
+                lds[cl * S + t] = src[idx];
+            }
+        }
+        __syncthreads();
+        for (int ph = 0; ph < nphase; ++ph) {
+            const PackArgs& a = batch.ph[ph];
+            if (col >= a.ld) continue;
+            const int T = a.TH * a.TW;
+            for (int r = 0; r < T; ++r) {
+                const int th = r / a.TW, tw = r - th * a.TW;
+                const int t = (a.kh0 + a.s * th) * a.KW + a.kw0 + a.s * tw;
+                a.out[((int64_t)m * T + r) * a.ld + col] = (int)threadIdx.x < cn ? lds[threadIdx.x * S + t] : 0.0f;
+            }
+        }
+        return;
+    }
+    for (int ph = 0; ph < nphase; ++ph) {
+        const PackArgs& a = batch.ph[ph];
+        if (col < a.ld)
+            for (int k = a.K; k < a.rows; ++k) a.out[(int64_t)k * a.ld + col] = 0.0f;
+        if (blockIdx.x == 0)
+            for (int k = threadIdx.x; k < a.rows; k += 256) pack_tables(a, k);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM gather kernel:
 //   out[b, m, oy, ox] = scale * sum_k wp[k][m] * in[b, :, qy*istride, qx*istride][koff[k]]  (+ bias[m])
@@ -416,7 +491,13 @@ static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const cha
         const int64_t t = (int64_t)b.ph[i].rows * b.ph[i].ld;
         if (t > big) big = t;
     }
-    pack_weights_kernel<<<dim3(stream_grid(big, 256), nphase), 256, 0, st>>>(b);
+    const PackArgs& a0 = b.ph[0];
+    if (a0.mode == 0 && nphase == 1)
+        pack_transpose_kernel<<<dim3((a0.rows + 63) / 64, (a0.ld + 63) / 64), 256, 0, st>>>(a0);
+    else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS)
+        pack_adjoint_kernel<<<dim3((a0.ld + 255) / 256, a0.M + 1), 256, 0, st>>>(b, nphase);
+    else
+        pack_weights_kernel<<<dim3(stream_grid(big, 256), nphase), 256, 0, st>>>(b);
     LOCATE_LAUNCH_CHECK(who);
     return LOCATE_OK;
 }

@@ -119,12 +119,15 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__
     }
 }
 
-// One wave per plane: dx, da (full) and the per-plane sums  sum x*g  and  sum x^2*g.
+// One wave per plane: dx, da (full, or gamma * sum x*g per plane in broadcast mode) and, per BLOCK, the sum of
+// x^2*g over the planes the block visited (fixed order: deterministic).
 __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                              const float* __restrict__ gamma, const float* __restrict__ g,
                                                              float* __restrict__ dx, float* __restrict__ da_full,
-                                                             float* __restrict__ plane_xg, float* __restrict__ plane_x2g,
+                                                             float* __restrict__ da_plane, double* __restrict__ block_x2g,
                                                              int64_t planes, int hw, int a_per_plane) {
+    __shared__ double wsum[4];
+    double wacc = 0.0;
     const float gm = gamma[0];
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -144,25 +147,20 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
         }
         sxg = wave_sum(sxg);
         sx2g = wave_sum(sx2g);
-        if (lane == 0) {
-            plane_xg[p] = sxg;
-            plane_x2g[p] = sx2g;
-        }
+        wacc += (double)sx2g;
+        if (lane == 0 && a_per_plane) da_plane[p] = gm * sxg;
     }
+    if (lane == 0) wsum[threadIdx.x >> 6] = wacc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_x2g[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// dgamma = sum_p plane_x2g[p] (reference bug: x^2 g, merge.py:33-38);  da[p] = gamma * plane_xg[p] (broadcast mode)
-__global__ void __launch_bounds__(1024) gate_bwd_final_kernel(const float* __restrict__ plane_xg,
-                                                              const float* __restrict__ plane_x2g,
-                                                              const float* __restrict__ gamma, float* __restrict__ da_plane,
-                                                              float* __restrict__ dgamma, int64_t planes, int a_per_plane) {
+// dgamma = sum over blocks of block_x2g (reference bug: x^2 g, merge.py:33-38)
+__global__ void __launch_bounds__(256) gate_bwd_final_kernel(const double* __restrict__ block_x2g, float* __restrict__ dgamma,
+                                                             int nblocks) {
     __shared__ double scratch[16];
-    const float gm = gamma[0];
     double acc = 0.0;
-    for (int64_t p = threadIdx.x; p < planes; p += blockDim.x) {
-        acc += (double)plane_x2g[p];
-        if (a_per_plane) da_plane[p] = gm * plane_xg[p];
-    }
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += block_x2g[i];
     acc = block_sum<double>(acc, scratch);
     if (threadIdx.x == 0) dgamma[0] = (float)acc;
 }
@@ -177,22 +175,21 @@ LOCATE_API int locate_gate_fwd(const float* x, const float* a, int a_per_plane, 
     return LOCATE_OK;
 }
 
-LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { return (size_t)planes * 2 * sizeof(float); }
+LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { (void)planes; return 4096 * sizeof(double); }
 
 // da: [planes*hw] when a_per_plane == 0, [planes] otherwise.  dgamma: one float (overwritten).
 LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g,
                                float* dx, float* da, float* dgamma, int64_t planes, int hw, void* workspace,
                                void* stream) {
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
-    float* plane_xg = static_cast<float*>(workspace);
-    float* plane_x2g = plane_xg + planes;
+    double* block_x2g = static_cast<double*>(workspace);
     int64_t blocks = cdiv64(planes, 4);
     if (blocks > 4096) blocks = 4096;
     gate_bwd_plane_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
-                                                                     plane_xg, plane_x2g, planes, hw, a_per_plane);
+                                                                     a_per_plane ? da : nullptr, block_x2g, planes, hw,
+                                                                     a_per_plane);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
-    gate_bwd_final_kernel<<<1, 1024, 0, as_stream(stream)>>>(plane_xg, plane_x2g, gamma, a_per_plane ? da : nullptr,
-                                                            dgamma, planes, a_per_plane);
+    gate_bwd_final_kernel<<<1, 256, 0, as_stream(stream)>>>(block_x2g, dgamma, (int)blocks);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(final)");
     return LOCATE_OK;
 }

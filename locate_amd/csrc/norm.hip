@@ -225,64 +225,59 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
     }
 }
 
-// One block, deterministic (fixed summation order - no atomics - so that eager and hipGraph replays agree bit for
-// bit): thread (c, slot) sums its share of the batch for channel c, the slots meet through LDS in a fixed order.
-__global__ void __launch_bounds__(1024) norm_bwd_final_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
-                                                              const float* __restrict__ stats, const float* __restrict__ scale,
-                                                              int scale_per_sample, float* __restrict__ dscale,
-                                                              float* __restrict__ dbias, float* __restrict__ consts, int B,
-                                                              int C, int hw, int groups) {
+// Deterministic (fixed summation order - no atomics - so that eager and hipGraph replays agree bit for bit).
+// Block = 16 channels x 16 batch slots; the slots meet through LDS in a fixed order.  Per block and group the partial
+// sums of y*S1 and y*S2 go to `partial` [blocks][NORM_MAX_GROUPS][2] (double); the dx kernel adds them up.
+constexpr int NF_CH = 16, NF_SLOTS = 16;
+__global__ void __launch_bounds__(256) norm_bwd_final_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const float* __restrict__ stats, const float* __restrict__ scale,
+                                                             int scale_per_sample, float* __restrict__ dscale,
+                                                             float* __restrict__ dbias, double* __restrict__ partial, int B,
+                                                             int C, int groups) {
     __shared__ double scratch[16];
-    __shared__ float part_b[1024], part_y[1024];
+    __shared__ float part_b[256], part_y[256];
     const int Bg = B / groups;
+    const int cl = threadIdx.x & (NF_CH - 1), slot = threadIdx.x / NF_CH;
+    const int c = blockIdx.x * NF_CH + cl;
     double sum_yg[NORM_MAX_GROUPS], sum_yxg[NORM_MAX_GROUPS];
 #pragma unroll
     for (int g = 0; g < NORM_MAX_GROUPS; ++g) sum_yg[g] = sum_yxg[g] = 0.0;
-    for (int c0 = 0; c0 < C; c0 += 1024) {                 // channel tiles of up to 1024 (one pass for every shipped width)
-        const int cw = min(1024, C - c0);
-        const int slots = max(1, 1024 / cw);
-        const int cl = threadIdx.x % cw, slot = threadIdx.x / cw;
-        float db = 0.0f, dy = 0.0f;
-        if (slot < slots) {
-            const int c = c0 + cl;
-            for (int b = slot; b < B; b += slots) {
-                const int grp = b / Bg;
-                const float sf = stats[2 * grp + 1];
-                const int64_t p = (int64_t)b * C + c;
-                const float s1 = S1[p], s2 = S2[p];
-                const float y = scale[scale_per_sample ? p : c];
-                db += s1;
-                if (scale_per_sample) dscale[p] = s2 / sf;
-                else dy += s2 / sf;
+    float db = 0.0f, dy = 0.0f;
+    if (c < C) {
+        for (int b = slot; b < B; b += NF_SLOTS) {
+            const int grp = b / Bg;
+            const float sf = stats[2 * grp + 1];
+            const int64_t p = (int64_t)b * C + c;
+            const float s1 = S1[p], s2 = S2[p];
+            const float y = scale[scale_per_sample ? p : c];
+            db += s1;
+            if (scale_per_sample) dscale[p] = s2 / sf;
+            else dy += s2 / sf;
 #pragma unroll
-                for (int g = 0; g < NORM_MAX_GROUPS; ++g)
-                    if (g == grp) {
-                        sum_yg[g] += (double)y * (double)s1;
-                        sum_yxg[g] += (double)y * (double)s2;
-                    }
-            }
-        }
-        __syncthreads();
-        if (slot < slots) { part_b[slot * cw + cl] = db; part_y[slot * cw + cl] = dy; }
-        __syncthreads();
-        if ((int)threadIdx.x < cw) {
-            float tb = 0.0f, ty = 0.0f;
-            for (int g2 = 0; g2 < slots; ++g2) { tb += part_b[g2 * cw + threadIdx.x]; ty += part_y[g2 * cw + threadIdx.x]; }
-            dbias[c0 + threadIdx.x] = tb;
-            if (!scale_per_sample) dscale[c0 + threadIdx.x] = ty;
+            for (int g = 0; g < NORM_MAX_GROUPS; ++g)
+                if (g == grp) {
+                    sum_yg[g] += (double)y * (double)s1;
+                    sum_yxg[g] += (double)y * (double)s2;
+                }
         }
     }
-    const double n = (double)Bg * (double)C * (double)hw;     // elements per group
+    part_b[threadIdx.x] = db;
+    part_y[threadIdx.x] = dy;
+    __syncthreads();
+    if (slot == 0 && c < C) {
+        float tb = 0.0f, ty = 0.0f;
+        for (int s2 = 0; s2 < NF_SLOTS; ++s2) { tb += part_b[s2 * NF_CH + cl]; ty += part_y[s2 * NF_CH + cl]; }
+        dbias[c] = tb;
+        if (!scale_per_sample) dscale[c] = ty;
+    }
 #pragma unroll
     for (int g = 0; g < NORM_MAX_GROUPS; ++g) {
         if (g >= groups) break;
         const double a = block_sum<double>(sum_yg[g], scratch);
         const double b2 = block_sum<double>(sum_yxg[g], scratch);
         if (threadIdx.x == 0) {
-            const double s = (double)stats[2 * g + 1];
-            const double dz = -b2 / (s * s);
-            consts[2 * g] = (float)(a / s / n);
-            consts[2 * g + 1] = (float)(dz / ((n - 1.0) * s));
+            partial[((int64_t)blockIdx.x * NORM_MAX_GROUPS + g) * 2] = a;
+            partial[((int64_t)blockIdx.x * NORM_MAX_GROUPS + g) * 2 + 1] = b2;
         }
     }
 }
@@ -291,12 +286,28 @@ template <bool ACT>
 __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ stats, const float* __restrict__ scale,
                                                           int scale_per_sample, const float* __restrict__ bias,
-                                                          const float* __restrict__ consts, float* __restrict__ dx,
-                                                          int64_t planes_g, int C, int hw) {
+                                                          const double* __restrict__ partial, int npartial,
+                                                          float* __restrict__ dx, int64_t planes_g, int C, int hw) {
+    __shared__ float consts[2];
     const int grp = blockIdx.y;
     const float mu = stats[2 * grp], s = stats[2 * grp + 1];
-    const float m = consts[2 * grp], k = consts[2 * grp + 1];
     const int64_t n = planes_g * hw;
+    if (threadIdx.x < 64) {           // { mean(y go / s), dz / ((N - 1) s) } of this group from the per-block partials
+        double a = 0.0, b2 = 0.0;
+        for (int i = threadIdx.x; i < npartial; i += 64) {
+            a += partial[((int64_t)i * NORM_MAX_GROUPS + grp) * 2];
+            b2 += partial[((int64_t)i * NORM_MAX_GROUPS + grp) * 2 + 1];
+        }
+        a = wave_sum_d(a);
+        b2 = wave_sum_d(b2);
+        if (threadIdx.x == 0) {
+            const double sd = (double)s, nn = (double)n;
+            consts[0] = (float)(a / sd / nn);
+            consts[1] = (float)(-b2 / (sd * sd) / ((nn - 1.0) * sd));
+        }
+    }
+    __syncthreads();
+    const float m = consts[0], k = consts[1];
     x += (int64_t)grp * n; g += (int64_t)grp * n; dx += (int64_t)grp * n;
     const int64_t plane0 = (int64_t)grp * planes_g;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -330,7 +341,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
 }
 
 LOCATE_API size_t locate_norm_bwd_workspace_bytes(int B, int C) {
-    return ((size_t)B * C * 2 + 2 * NORM_MAX_GROUPS + 4) * sizeof(float);
+    return (size_t)((C + NF_CH - 1) / NF_CH) * NORM_MAX_GROUPS * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
 }
 
 // dscale: [C] (scale_per_sample = 0) or [B*C];  dbias: [C].  Both overwritten.  stats: [groups][2] from the forward.
@@ -345,9 +356,10 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd: with_act needs the bias");
     const int64_t planes = (int64_t)B * C, planes_g = planes / groups;
     LOCATE_REQUIRE(groups == 1 || ((planes_g * hw) & 3) == 0, "locate_norm_bwd: grouped tensors need a group size that is a multiple of 4");
-    float* S1 = static_cast<float*>(workspace);
+    const int nfb = (C + NF_CH - 1) / NF_CH;
+    double* partial = static_cast<double*>(workspace);
+    float* S1 = reinterpret_cast<float*>(partial + (size_t)nfb * NORM_MAX_GROUPS * 2);
     float* S2 = S1 + planes;
-    float* consts = S2 + planes;
     int64_t blocks = cdiv64(planes, 4);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = as_stream(stream);
@@ -356,13 +368,13 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     else
         norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(plane)");
-    norm_bwd_final_kernel<<<1, 1024, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, consts, B, C, hw, groups);
+    norm_bwd_final_kernel<<<nfb, 256, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, partial, B, C, groups);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
     const dim3 grid(stream_grid(planes_g * hw, 1024), groups);
     if (with_act)
-        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes_g, C, hw);
+        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw);
     else
-        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, consts, dx, planes_g, C, hw);
+        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
     return LOCATE_OK;
 }

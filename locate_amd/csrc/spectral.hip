@@ -47,7 +47,15 @@ __global__ void __launch_bounds__(SN_COLS) sn_colsum_kernel(const SnLayer single
     const int i1 = min(i0 + SN_ROWS, L.h);
     if (col >= L.wd) return;
     float acc = 0.0f;
-    for (int i = i0; i < i1; ++i) acc = fmaf(L.w[(int64_t)i * L.wd + col], L.u[i], acc);
+    int i = i0;
+    for (; i + 8 <= i1; i += 8) {          // 8 independent loads in flight, summed in row order
+        float wv8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv8[k] = L.w[(int64_t)(i + k) * L.wd + col];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = fmaf(wv8[k], L.u[i + k], acc);
+    }
+    for (; i < i1; ++i) acc = fmaf(L.w[(int64_t)i * L.wd + col], L.u[i], acc);
     L.tpart[(int64_t)chunk * L.wd + col] = acc;
 }
 
@@ -62,16 +70,45 @@ __global__ void __launch_bounds__(SN_COLS) sn_tsum_kernel(const SnLayer single, 
     L.t[col] = acc;
 }
 
-// s[row] = W[row, :] . t     (one wave per row)
+// s[row] = W[row, :] . t.   Wide layers (wd >= SN_WIDE): one block per row; narrow layers: one wave per row.
+#define SN_WIDE 1024
+__device__ __forceinline__ float sn_row_partial(const float* __restrict__ wr, const float* __restrict__ t, int wd, int first,
+                                                int step) {
+    float acc = 0.0f;
+    if ((wd & 3) == 0 && ((reinterpret_cast<uintptr_t>(wr) & 15) == 0)) {
+        const float4* w4 = reinterpret_cast<const float4*>(wr);
+        const bool t_al = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+        for (int j = first; j < (wd >> 2); j += step) {
+            const float4 a = w4[j];
+            float4 b;
+            if (t_al) b = reinterpret_cast<const float4*>(t)[j];
+            else { b.x = t[4 * j]; b.y = t[4 * j + 1]; b.z = t[4 * j + 2]; b.w = t[4 * j + 3]; }
+            acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+    } else {
+        for (int j = first; j < wd; j += step) acc = fmaf(wr[j], t[j], acc);
+    }
+    return acc;
+}
+
 template <bool BATCHED>
 __global__ void __launch_bounds__(256) sn_rowdot_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+    __shared__ float wsum[4];
     const SnLayer L = sn_get<BATCHED>(single, table);
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (L.wd >= SN_WIDE) {
+        const int row = blockIdx.x;
+        if (row >= L.h) return;
+        float acc = sn_row_partial(L.w + (int64_t)row * L.wd, L.t, L.wd, threadIdx.x, 256);
+        acc = wave_sum(acc);
+        if (lane == 0) wsum[wid] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) L.s[row] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        return;
+    }
+    const int row = blockIdx.x * 4 + wid;
     if (row >= L.h) return;
-    const int lane = threadIdx.x & 63;
-    const float* wr = L.w + (int64_t)row * L.wd;
-    float acc = 0.0f;
-    for (int j = lane; j < L.wd; j += 64) acc = fmaf(wr[j], L.t[j], acc);
+    float acc = sn_row_partial(L.w + (int64_t)row * L.wd, L.t, L.wd, lane, 64);
     acc = wave_sum(acc);
     if (lane == 0) L.s[row] = acc;
 }
@@ -137,7 +174,7 @@ LOCATE_API int locate_sn_power_iter(const float* w, float* u, float* v, float* s
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(colsum)");
     sn_tsum_kernel<false><<<nstrip, SN_COLS, 0, st>>>(L, nullptr);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(tsum)");
-    sn_rowdot_kernel<false><<<(h + 3) / 4, 256, 0, st>>>(L, nullptr);
+    sn_rowdot_kernel<false><<<wd >= SN_WIDE ? h : (h + 3) / 4, 256, 0, st>>>(L, nullptr);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(rowdot)");
     sn_finalize_kernel<false><<<1, 256, 0, st>>>(L, nullptr);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(finalize)");
@@ -159,7 +196,7 @@ LOCATE_API int locate_sn_power_iter_batched(const void* table, int n_layers, int
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(colsum)");
     sn_tsum_kernel<true><<<dim3(nstrip, n_layers), SN_COLS, 0, st>>>(dummy, tab);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(tsum)");
-    sn_rowdot_kernel<true><<<dim3((max_h + 3) / 4, n_layers), 256, 0, st>>>(dummy, tab);
+    sn_rowdot_kernel<true><<<dim3(max_wd >= SN_WIDE ? max_h : (max_h + 3) / 4, n_layers), 256, 0, st>>>(dummy, tab);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(rowdot)");
     sn_finalize_kernel<true><<<dim3(1, n_layers), 256, 0, st>>>(dummy, tab);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(finalize)");
