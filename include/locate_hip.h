@@ -115,6 +115,12 @@ int locate_sn_dv_batched(const void* table, int n_layers, int max_h, int max_wd,
  *      libs/spectral_norm.py:31-32); *_bs are batch strides in elements; workspace = split-K slabs (may be 0). ---- */
 size_t locate_conv_panel_bytes(const int* geom, int adjoint);
 int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* panel, void* stream);
+/* all panels of a network in one launch (after an optimizer step): one HOST record of locate_conv_pack_job_bytes()
+ * per panel, filled by locate_conv_pack_job (block_start = running sum of *blocks_out), uploaded by the caller */
+size_t locate_conv_pack_job_bytes(void);
+int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
+                         int* blocks_out);
+int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
 /* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride] */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,

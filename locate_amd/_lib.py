@@ -57,6 +57,9 @@ PROTOTYPES = {
     "locate_sn_dv_batched": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_conv_panel_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
+    "locate_conv_pack_job_bytes": (c_sz, []),
+    "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip]),
+    "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),

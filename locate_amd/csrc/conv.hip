@@ -21,6 +21,8 @@
 // Tiling: 256 threads = 4 waves, block tile BM x 128 (BM in {128, 96, 64, 32}), K step 16, double-buffered
 // LDS with register prefetch of the next K step, one barrier per step.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -78,12 +80,31 @@ struct PackBatch {
     PackArgs ph[4];
 };
 
-__global__ void __launch_bounds__(256) pack_weights_kernel(const PackBatch batch) {
-    const PackArgs& a = batch.ph[blockIdx.y];
-    const int64_t total = (int64_t)a.rows * a.ld;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ void pack_tables(const PackArgs& a, int k) {
+    int* koff = reinterpret_cast<int*>(a.out + (size_t)a.rows * a.ld);
+    unsigned char* ktap = reinterpret_cast<unsigned char*>(koff + a.rows);
     const int T = a.TH * a.TW;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int off = 0, tap = 31;
+    if (k < a.K && T > 0) {
+        const int c = k / T, t = k - c * T;
+        const int th = t / a.TW, tw = t - th * a.TW;
+        off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
+        tap = t;
+    }
+    koff[k] = off;
+    ktap[k] = (unsigned char)tap;
+}
+
+#define PACK_MAX_TAPS 32
+#define PACK_SMEM (256 * (PACK_MAX_TAPS + 1))      // floats; also holds the 64 x 65 transpose tile
+
+// generic element-wise form (any tap count): virtual grid (nbx, nphase)
+__device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx, int by, int nbx) {
+    const PackArgs& a = batch.ph[by];
+    const int64_t total = (int64_t)a.rows * a.ld;
+    const int64_t stride = (int64_t)nbx * 256;
+    const int T = a.TH * a.TW;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
         const int k = (int)(i / a.ld), col = (int)(i - (int64_t)k * a.ld);
         float v = 0.0f;
         if (k < a.K) {
@@ -103,41 +124,14 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackBatch batch
         }
         a.out[i] = v;
     }
-    int* koff = reinterpret_cast<int*>(a.out + (size_t)a.rows * a.ld);
-    unsigned char* ktap = reinterpret_cast<unsigned char*>(koff + a.rows);
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.rows; k += stride) {
-        int off = 0, tap = 31;
-        if (k < a.K && T > 0) {
-            const int c = (int)k / T, t = (int)k - c * T;
-            const int th = t / a.TW, tw = t - th * a.TW;
-            off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
-            tap = t;
-        }
-        koff[k] = off;
-        ktap[k] = (unsigned char)tap;
-    }
-}
-
-__device__ __forceinline__ void pack_tables(const PackArgs& a, int k) {
-    int* koff = reinterpret_cast<int*>(a.out + (size_t)a.rows * a.ld);
-    unsigned char* ktap = reinterpret_cast<unsigned char*>(koff + a.rows);
-    const int T = a.TH * a.TW;
-    int off = 0, tap = 31;
-    if (k < a.K && T > 0) {
-        const int c = k / T, t = k - c * T;
-        const int th = t / a.TW, tw = t - th * a.TW;
-        off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
-        tap = t;
-    }
-    koff[k] = off;
-    ktap[k] = (unsigned char)tap;
+    for (int64_t k = (int64_t)bx * 256 + threadIdx.x; k < a.rows; k += stride) pack_tables(a, (int)k);
 }
 
 // mode 0 (R forward): the panel is the transpose of W viewed as [M][K]: 64 x 64 tiles through LDS, both the read
-// (along k) and the write (along m) are coalesced.  grid (rows / 64, ld / 64).
-__global__ void __launch_bounds__(256) pack_transpose_kernel(const PackArgs a) {
-    __shared__ float tile[64][65];
-    const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+// (along k) and the write (along m) are coalesced.  virtual grid (rows / 64, ld / 64).
+__device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, int by, float* smem) {
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(smem);
+    const int k0 = bx * 64, m0 = by * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int j = ty; j < 64; j += 4) {
         const int m = m0 + j, k = k0 + tx;
@@ -148,18 +142,16 @@ __global__ void __launch_bounds__(256) pack_transpose_kernel(const PackArgs a) {
         const int k = k0 + j, m = m0 + tx;
         if (k < a.rows && m < a.ld) a.out[(int64_t)k * a.ld + m] = tile[tx][j];
     }
-    if (blockIdx.y == 0 && threadIdx.x < 64 && k0 + (int)threadIdx.x < a.rows) pack_tables(a, k0 + threadIdx.x);
+    if (by == 0 && threadIdx.x < 64 && k0 + (int)threadIdx.x < a.rows) pack_tables(a, k0 + threadIdx.x);
 }
 
 // mode 1 (data adjoint, all sub-pixel phases at once): for one m, W[m] is a [C][KH*KW] matrix; a block stages 256
 // channels of it in LDS (contiguous read) and writes, per tap, one 256-wide piece of the row (m, tap) of the phase
-// that owns the tap.  blockIdx.y == M: zero tail rows and the offset tables.  grid (ld / 256, M + 1).
-#define PACK_MAX_TAPS 32
-__global__ void __launch_bounds__(256) pack_adjoint_kernel(const PackBatch batch, int nphase) {
-    __shared__ float lds[256 * (PACK_MAX_TAPS + 1)];
+// that owns the tap.  by == M: zero tail rows and the offset tables.  virtual grid (ld / 256, M + 1).
+__device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int nphase, int bx, int by, float* lds) {
     const PackArgs& a0 = batch.ph[0];
     const int KK = a0.KH * a0.KW, S = KK | 1;
-    const int m = blockIdx.y, c0 = blockIdx.x * 256;
+    const int m = by, c0 = bx * 256;
     const int col = c0 + threadIdx.x;
     if (m < a0.M) {
         const int cn = min(256, a0.C - c0);
@@ -188,9 +180,61 @@ __global__ void __launch_bounds__(256) pack_adjoint_kernel(const PackBatch batch
         const PackArgs& a = batch.ph[ph];
         if (col < a.ld)
             for (int k = a.K; k < a.rows; ++k) a.out[(int64_t)k * a.ld + col] = 0.0f;
-        if (blockIdx.x == 0)
+        if (bx == 0)
             for (int k = threadIdx.x; k < a.rows; k += 256) pack_tables(a, k);
     }
+}
+
+// One packing job = all phases of one panel; `kind` selects the body, (gx, gy) is its virtual grid.
+struct PackJob {
+    PackBatch batch;
+    int nphase, kind;          // kind 0: transpose, 1: adjoint, 2: generic
+    int gx, gy;
+    int block_start, pad;      // first block of this job inside a batched launch
+};
+
+static PackJob make_pack_job(const PackBatch& b, int nphase) {
+    PackJob j;
+    j.batch = b; j.nphase = nphase; j.block_start = 0; j.pad = 0;
+    const PackArgs& a0 = b.ph[0];
+    if (a0.mode == 0 && nphase == 1) {
+        j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
+    } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS) {
+        j.kind = 1; j.gx = (a0.ld + 255) / 256; j.gy = a0.M + 1;
+    } else {
+        int64_t big = 1;
+        for (int i = 0; i < nphase; ++i) {
+            const int64_t t = (int64_t)b.ph[i].rows * b.ph[i].ld;
+            if (t > big) big = t;
+        }
+        j.kind = 2; j.gx = stream_grid(big, 256); j.gy = nphase;
+    }
+    return j;
+}
+
+__device__ __forceinline__ void pack_job_body(const PackJob& j, int local, float* smem) {
+    const int bx = local % j.gx, by = local / j.gx;
+    if (j.kind == 0) pack_transpose_body(j.batch.ph[0], bx, by, smem);
+    else if (j.kind == 1) pack_adjoint_body(j.batch, j.nphase, bx, by, smem);
+    else pack_generic_body(j.batch, bx, by, j.gx);
+}
+
+__global__ void __launch_bounds__(256) pack_job_kernel(const PackJob job) {
+    __shared__ float smem[PACK_SMEM];
+    pack_job_body(job, blockIdx.x, smem);
+}
+
+// many panels in one launch: `jobs` (device) sorted by block_start; a block finds its job by bisection
+__global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float smem[PACK_SMEM];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob& j = jobs[lo];
+    pack_job_body(j, blockIdx.x - j.block_start, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -435,6 +479,101 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1, no padding) contraction with few channels on both sides (K, M <= 64) over many pixels:
+// an HBM-bound stream (the self-attention gates at 64x64 read and write 50 MB each for ~1 GFLOP), where the
+// tile machinery of the MFMA kernel costs more than the arithmetic.  One thread = 2 adjacent pixels x all output
+// channels; the weight row of each k is wave-uniform and comes through scalar loads; 8-byte coalesced loads / stores.
+//   out[b, m, q] = scale_g(b) * sum_k wp[k][m] * in[b, k, q] (+ bias[m])
+// ---------------------------------------------------------------------------------------------
+template <int MT, int PX>
+__global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
+    const IgPhase& ph = p.ph[0];
+    const int HW = p.H * p.W;
+    const long long npx = (long long)p.B * HW / PX;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const long long n = PX * i;
+    const int b = (int)(n / HW), q = (int)(n - (long long)b * HW);
+    const float* ip = p.in + (long long)b * p.in_bs + q;
+    const float* __restrict__ wp = ph.wp;
+    const int ld = ph.ld, K = ph.K;
+    float acc[MT][PX];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < PX; ++e) acc[m][e] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        float xv[4][PX];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = min(k0 + kk, K - 1);          // rows >= K of the panel are zero
+            const float* xp = ip + (long long)k * HW;
+            if (PX == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(xp);
+                xv[kk][0] = t.x; xv[kk][PX - 1] = t.y;
+            } else {
+                xv[kk][0] = *xp;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float* wr = wp + (long long)(k0 + kk) * ld;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float wv = wr[m];
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[m][e] = fmaf(wv, xv[kk][e], acc[m][e]);
+            }
+        }
+    }
+    const float sc = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
+    float* op = p.out + (long long)b * p.out_bs + q;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < p.M) {
+            const float bv = p.bias ? p.bias[m] : 0.0f;
+            if (PX == 2)
+                *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(fmaf(acc[m][0], sc, bv), fmaf(acc[m][PX - 1], sc, bv));
+            else
+                op[(long long)m * HW] = fmaf(acc[m][0], sc, bv);
+        }
+    }
+}
+
+// debugging knob for A/B timing inside one process environment: LOCATE_DISABLE=pointwise,...
+static bool path_disabled(const char* name) {
+    static const char* env = getenv("LOCATE_DISABLE");
+    return env != nullptr && strstr(env, name) != nullptr;
+}
+
+static bool pointwise_ok(const IgParams& p) {
+    if (p.nphase != 1 || path_disabled("pointwise")) return false;
+    const IgPhase& ph = p.ph[0];
+    const int HW = p.H * p.W;
+    return ph.T == 1 && p.istride == 1 && p.ostep == 1 && ph.dy0 == 0 && ph.dx0 == 0 && p.H == p.OH && p.W == p.OW &&
+           ph.K >= 1 && ph.K <= 64 && p.M <= 64 && ph.ld >= ((p.M + 15) / 16) * 16 && (HW & 1) == 0 && (p.in_bs & 1) == 0 &&
+           (p.out_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(p.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 7) == 0 &&
+           (long long)p.B * HW >= 131072;
+}
+
+template <int PX>
+static void launch_pointwise_px(const IgParams& p, hipStream_t st) {
+    const long long npx = (long long)p.B * p.H * p.W / PX;
+    const int blocks = (int)((npx + 255) / 256);
+    const int mt = (p.M + 15) / 16;
+    if (mt == 1) conv_pointwise_kernel<16, PX><<<blocks, 256, 0, st>>>(p);
+    else if (mt == 2) conv_pointwise_kernel<32, PX><<<blocks, 256, 0, st>>>(p);
+    else if (mt == 3) conv_pointwise_kernel<48, PX><<<blocks, 256, 0, st>>>(p);
+    else conv_pointwise_kernel<64, PX><<<blocks, 256, 0, st>>>(p);
+}
+
+static void launch_pointwise(const IgParams& p, hipStream_t st) {
+    // two pixels per thread only when that still leaves >= 4 blocks per CU
+    if ((long long)p.B * p.H * p.W >= 2ll * 256 * 1024) launch_pointwise_px<2>(p, st);
+    else launch_pointwise_px<1>(p, st);
+}
+
 static int pick_bm(int M) {
     const int cands[4] = {128, 96, 64, 32};
     int best = 128, best_pad = 1 << 30;
@@ -461,6 +600,12 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
 }
 
 static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, const char* who) {
+    if (pointwise_ok(p)) {
+        p.ksplit = 1;
+        launch_pointwise(p, st);
+        LOCATE_LAUNCH_CHECK(who);
+        return LOCATE_OK;
+    }
     const int bm = pick_bm(p.M);
     int min_kpad = 1 << 30;
     for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
@@ -484,20 +629,10 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     return LOCATE_OK;
 }
 
-// all phases of one panel in a single launch (blockIdx.y = phase)
+// all phases of one panel in a single launch
 static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const char* who) {
-    int64_t big = 1;
-    for (int i = 0; i < nphase; ++i) {
-        const int64_t t = (int64_t)b.ph[i].rows * b.ph[i].ld;
-        if (t > big) big = t;
-    }
-    const PackArgs& a0 = b.ph[0];
-    if (a0.mode == 0 && nphase == 1)
-        pack_transpose_kernel<<<dim3((a0.rows + 63) / 64, (a0.ld + 63) / 64), 256, 0, st>>>(a0);
-    else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS)
-        pack_adjoint_kernel<<<dim3((a0.ld + 255) / 256, a0.M + 1), 256, 0, st>>>(b, nphase);
-    else
-        pack_weights_kernel<<<dim3(stream_grid(big, 256), nphase), 256, 0, st>>>(b);
+    const PackJob j = make_pack_job(b, nphase);
+    pack_job_kernel<<<j.gx * j.gy, 256, 0, st>>>(j);
     LOCATE_LAUNCH_CHECK(who);
     return LOCATE_OK;
 }
@@ -540,7 +675,7 @@ static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
 // `panel` is the packed-weight buffer (may be null when only sizes are wanted); with `pack` the packing kernels
 // are launched.  Returns the panel size in floats and the largest per-phase N.
 static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* panel, IgParams& p, int* nmax_out,
-                     size_t* panel_floats_out, bool pack, hipStream_t st) {
+                     size_t* panel_floats_out, bool pack, hipStream_t st, PackBatch* batch_out = nullptr) {
     size_t off = 0;
     int nmax = 0;
     p.nphase = 0;
@@ -590,6 +725,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
     }
     if (nmax_out) *nmax_out = nmax;
     if (panel_floats_out) *panel_floats_out = off;
+    if (batch_out) *batch_out = batch;
     if (pack && p.nphase > 0)
         if (int e = launch_pack(batch, p.nphase, st, "locate_conv_pack_panel")) return e;
     return LOCATE_OK;
@@ -612,6 +748,34 @@ LOCATE_API int locate_conv_pack_panel(const int* geom, int adjoint, const float*
     LOCATE_REQUIRE(w && panel, "locate_conv_pack_panel: null pointer");
     IgParams p;
     return conv_plan(g, adjoint, w, panel, p, nullptr, nullptr, true, as_stream(stream));
+}
+
+// Batched form (all panels of a network in ONE launch after an optimizer step): the caller fills one host record per
+// panel with locate_conv_pack_job (block_start = running sum of the returned block counts), uploads the array and
+// calls locate_conv_pack_panels.  Records hold raw pointers: rebuild them when a weight or panel buffer moves.
+LOCATE_API size_t locate_conv_pack_job_bytes(void) { return sizeof(PackJob); }
+
+LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
+                                    int* blocks_out) {
+    const ConvGeom g = make_geom(geom);
+    if (int e = geom_check(g, "locate_conv_pack_job")) return e;
+    LOCATE_REQUIRE(w && panel && job_out && blocks_out && block_start >= 0, "locate_conv_pack_job: bad arguments");
+    IgParams p;
+    PackBatch batch;
+    if (int e = conv_plan(g, adjoint, w, panel, p, nullptr, nullptr, false, nullptr, &batch)) return e;
+    LOCATE_REQUIRE(p.nphase > 0, "locate_conv_pack_job: empty panel");
+    PackJob j = make_pack_job(batch, p.nphase);
+    j.block_start = block_start;
+    memcpy(job_out, &j, sizeof(PackJob));
+    *blocks_out = j.gx * j.gy;
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream) {
+    LOCATE_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "locate_conv_pack_panels: bad arguments");
+    pack_jobs_kernel<<<total_blocks, 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
+    LOCATE_LAUNCH_CHECK("locate_conv_pack_panels");
+    return LOCATE_OK;
 }
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,

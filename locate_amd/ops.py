@@ -457,23 +457,46 @@ def _finalize_pending_dv():
             v.grad.add_(st["dv"])
 
 
+class _PackPlans:
+    cache = {}       # signature of the stale set -> (device job table, n_jobs, total_blocks)
+
+
 def refresh_panels(params):
-    """Re-pack, on the current stream, every cached weight panel of `params` whose weight has changed since it was
-    packed.  Needed before work that uses the same layers concurrently on several streams (the pack is otherwise done
-    lazily by the first user, on that user's stream)."""
+    """Re-pack, on the current stream and in ONE launch, every cached weight panel of `params` whose weight has
+    changed since it was packed (called after an optimizer step; otherwise the first user of a layer re-packs its
+    panel lazily, one small launch per panel)."""
+    import ctypes
     L = lib()
+    stale = []
     for w in params:
         cache = w.__dict__.get("_locate_panels")
         if not cache:
             continue
         ver = w._version
-        for key, (pver, buf, geom) in list(cache.items()):
-            if pver != ver and buf.device == w.device:
-                wc = w.detach()
-                if not wc.is_contiguous():
-                    continue
-                check(L.locate_conv_pack_panel(_geom(geom), key[0], _p(wc), _p(buf), _stream()), "locate_conv_pack_panel")
-                cache[key] = (ver, buf, geom)
+        for key, (pver, buf, geom) in cache.items():
+            if pver != ver and buf.device == w.device and w.is_contiguous():
+                stale.append((w, key, buf, geom))
+    if not stale:
+        return
+    sig = tuple((key[2], key[0], buf.data_ptr()) + tuple(geom) for _, key, buf, geom in stale)
+    plan = _PackPlans.cache.get(sig)
+    if plan is None:
+        rec = L.locate_conv_pack_job_bytes()
+        host = ctypes.create_string_buffer(rec * len(stale))
+        start = 0
+        for i, (w, key, buf, geom) in enumerate(stale):
+            nb = ctypes.c_int(0)
+            check(L.locate_conv_pack_job(_geom(geom), key[0], key[2], _p(buf), start, ctypes.addressof(host) + i * rec,
+                                         ctypes.byref(nb)), "locate_conv_pack_job")
+            start += nb.value
+        table = torch.frombuffer(host, dtype=torch.uint8).clone().to(stale[0][0].device)
+        plan = (table, len(stale), start)
+        if len(_PackPlans.cache) > 16:
+            _PackPlans.cache.clear()
+        _PackPlans.cache[sig] = plan
+    check(L.locate_conv_pack_panels(_p(plan[0]), plan[1], plan[2], _stream()), "locate_conv_pack_panels")
+    for w, key, buf, geom in stale:
+        w.__dict__["_locate_panels"][key] = (w._version, buf, geom)
 
 
 def sn_power_iteration(w_bar, u, v):

@@ -126,8 +126,14 @@ class TrainStep:
         return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
                 "d_gen": -d_fake.detach().view(-1), "generated": generated}
 
+    @staticmethod
+    def _repack(net):
+        from . import ops
+        ops.refresh_panels([p for p in net.parameters() if "_locate_panels" in p.__dict__])
+
     def d_optimizer(self):
         self.dis_opt.step()                        # :159
+        self._repack(self.dis)                     # all of D's weight panels in one launch
 
     def g_forward_backward(self, latent):
         gen, dis = self.gen, self.dis
@@ -149,6 +155,7 @@ class TrainStep:
 
     def g_optimizer(self):
         self.gen_opt.step()                        # :171
+        self._repack(self.gen)
 
     def d_step(self, latent, real, aug):
         out = self.d_forward_backward(latent, real, aug)

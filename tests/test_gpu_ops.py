@@ -267,6 +267,10 @@ CONV_CASES = [
     ("convT", 192, 192, 4, 2, 1, 1, 5, 3),    # odd sizes, BM = 96 x 2
     ("convT", 130, 130, 4, 2, 1, 1, 4, 4),    # ragged M
     ("convT", 96, 48, 1, 1, 0, 2, 8, 8),      # transposed 1x1 (weights [C_in, C_out, 1, 1])
+    ("conv", 48, 48, 1, 1, 0, 32, 64, 64),    # pointwise streaming kernel (self-attention gate at 64x64), MT = 48
+    ("conv", 48, 3, 1, 1, 0, 130, 64, 64),    # pointwise, M = 3, two pixels per thread
+    ("conv", 50, 64, 1, 1, 0, 128, 32, 34),   # pointwise, ragged K (50), MT = 64
+    ("convT", 32, 20, 1, 1, 0, 128, 32, 32),  # pointwise through the adjoint panel, MT = 32
 ]
 
 
