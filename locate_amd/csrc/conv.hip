@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define IG_BK 16            // K elements per main-loop step
 #define IG_KPAD 32          // panels are zero-padded to a multiple of this many K rows
-#define IG_TAIL 48          // extra zero rows after Kpad: the branch-free prefetch of the last steps stays in bounds
+#define IG_TAIL 112         // extra zero rows after Kpad: the branch-free prefetch of the last steps stays in bounds
 #define IG_MAXT 32
 
 struct ConvGeom {
@@ -57,9 +57,13 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // ---------------------------------------------------------------------------------------------
 // Weight panel of one phase (all sections in 4-byte units, one buffer):
 //   weights [rows][ld]   K-major, rows = Kpad + IG_TAIL, zero beyond K and beyond M
-//   koff    [rows]       int: offset of gathered row k = (c, t) inside one batch image of the gathered tensor,
-//                        c*H*W + dy(t)*W + dx(t)  (0 beyond K)
+//   koff    [rows]       int: BYTE offset of gathered row k = (c, t) inside one batch image of the gathered tensor,
+//                        4 (c*H*W + dy(t)*W + dx(t) - dmin), dmin = the most negative tap displacement, so that the
+//                        offsets are >= 0 (they go into the scalar offset of a buffer load whose descriptor starts
+//                        dmin elements before the tensor; 0 beyond K)
 //   ktap    [rows / 4]   bytes: tap index t of row k (31 beyond K: a tap that is never valid)
+//   w3      [3][rows / 8][ld][8]  bf16: the weights as three bf16 pieces w = h + m + l (exact), 8 consecutive k per
+//                        16-byte chunk = the A fragment of v_mfma_f32_32x32x16_bf16
 // The offset table turns the gather's per-element mixed-radix arithmetic (~230 ALU instructions per K step, which
 // cost a quarter of the kernel's throughput) into two wave-uniform scalar loads per step.
 // ---------------------------------------------------------------------------------------------
@@ -72,9 +76,12 @@ struct PackArgs {
     int kh0, kw0, s, TH, TW;
     int K, rows, ld;
     int gHW, gW, dy0, dys, dx0, dxs;   // geometry of the gathered tensor and of the tap grid
+    int dmin;                          // min over the taps of dy*gW + dx (<= 0)
 };
 
-static inline size_t panel_floats(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
+static inline size_t panel_floats(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4 + (size_t)rows * ld / 2 * 3; }
+static inline size_t panel_split_offset(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }   // floats
+__device__ __forceinline__ size_t panel_split_offset_dev(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
 
 struct PackBatch {
     PackArgs ph[4];
@@ -88,7 +95,7 @@ __device__ __forceinline__ void pack_tables(const PackArgs& a, int k) {
     if (k < a.K && T > 0) {
         const int c = k / T, t = k - c * T;
         const int th = t / a.TW, tw = t - th * a.TW;
-        off = c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
+        off = 4 * (c * a.gHW + (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw - a.dmin);
         tap = t;
     }
     koff[k] = off;
@@ -185,6 +192,38 @@ __device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int np
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = h + m + l exactly (3 x 8 significant bits cover fp32's 24): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = (__bf16)v[j];
+        const float r1 = v[j] - (float)h[j];
+        m[j] = (__bf16)r1;
+        l[j] = (__bf16)(r1 - (float)m[j]);
+    }
+}
+
+// second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k)
+__device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int nbx) {
+    const float* w = a.out;
+    uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld));
+    const int64_t total = (int64_t)(a.rows / 8) * a.ld;
+    const int64_t stride = (int64_t)nbx * 256;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
+        const int kb = (int)(i / a.ld), col = (int)(i - (int64_t)kb * a.ld);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w[(int64_t)(kb * 8 + j) * a.ld + col];
+        bf16x8 h, m, l;
+        split3_bf16x8(v, h, m, l);
+        w3[i] = *reinterpret_cast<uint4*>(&h);
+        w3[total + i] = *reinterpret_cast<uint4*>(&m);
+        w3[2 * total + i] = *reinterpret_cast<uint4*>(&l);
+    }
+}
+
 // One packing job = all phases of one panel; `kind` selects the body, (gx, gy) is its virtual grid.
 struct PackJob {
     PackBatch batch;
@@ -224,6 +263,17 @@ __global__ void __launch_bounds__(256) pack_job_kernel(const PackJob job) {
     pack_job_body(job, blockIdx.x, smem);
 }
 
+#define PACK_SPLIT_BLOCKS 256
+__global__ void __launch_bounds__(256) pack_split_kernel(const PackJob job) {
+    if ((int)blockIdx.y < job.nphase) pack_split_body(job.batch.ph[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+// blockIdx.y = job, blockIdx.z = phase
+__global__ void __launch_bounds__(256) pack_split_jobs_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob& j = jobs[blockIdx.y];
+    if ((int)blockIdx.z < j.nphase) pack_split_body(j.batch.ph[blockIdx.z], blockIdx.x, gridDim.x);
+}
+
 // many panels in one launch: `jobs` (device) sorted by block_start; a block finds its job by bisection
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
     __shared__ float smem[PACK_SMEM];
@@ -246,7 +296,10 @@ struct IgPhase {
     const float* wp;             // packed weights [rows][ld]
     const int* koff;             // [rows]
     const unsigned char* ktap;   // [rows]
+    const uint4* w3;             // [3][rows / 8][ld] chunks of 8 bf16 (see the panel layout)
+    long long w3_plane;          // chunks per plane
     int K, Kpad, ld, T;
+    int dmin;                    // the buffer descriptor of the gather starts dmin (<= 0) elements before the tensor
     int oy0, ox0, QH, QW;
     int TW, tw_magic;            // tap t = th*TW + tw, th = (t * tw_magic) >> 16  (exact for t < 32)
     int dy0, dys, dx0, dxs;      // tap (th, tw) reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw)
@@ -259,7 +312,11 @@ struct IgParams {
     const float* scale;  // multiplies the contraction (1/sigma of spectral norm) or null; one value, or one per GROUP of
     int scale_bg;        //   scale_bg consecutive batch elements (scale_bg = 0: a single value), scale_stride floats apart
     int scale_stride;
+    float* act_out;          // nullable: additionally receives RootTanh(out) (the activation that follows the conv)
+    const float* dact_src;   // nullable: out is multiplied by RootTanh'(dact_src) at the same position (the conv is the
+    long long act_bs, dact_bs;   //        data gradient of the layer that follows that activation); batch strides
     long long in_bs, out_bs;
+    unsigned in_bytes;   // extent of the gathered tensor view in bytes (< 2^31): bound of the gather's buffer descriptor
     int B, C, H, W;      // gathered tensor: C = reduction channels
     int M, OH, OW;       // produced tensor
     int istride, ostep, nphase;
@@ -269,9 +326,125 @@ struct IgParams {
     IgPhase ph[4];
 };
 
+// Shared epilogue of the implicit-GEMM kernels (both MFMA flavours have the same 32x32 accumulator layout).
+template <int WGM, int WGN, int TM, int TN, bool EPI>
+__device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN], int N, int n0,
+                                               int m0, int zsplit, int wm, int wn, int lane) {
+    const int lrow = lane >> 5, lcol = lane & 31;
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const long long plane = (long long)p.OH * p.OW;
+    const bool split = p.ksplit > 1;
+    const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
+    float col_scale[TN];           // 1/sigma of the column's group (the batch may stack several forwards)
+    float* actp[TN];               // EPI: same position in act_out / dact_src
+    const float* dptr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nj = n0 + (wn * TN + j) * 32 + lcol;
+        const int nn = nj < N ? nj : 0;
+        const int qhw = ph.QH * ph.QW;
+        const int b = nn / qhw, q = nn - b * qhw;
+        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
+        const int qy = q / ph.QW, qx = q - qy * ph.QW;
+        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
+        const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
+                               : p.out + (long long)b * p.out_bs + pix;
+        optr[j] = nj < N ? o : nullptr;
+        if (EPI) {
+            actp[j] = p.act_out ? p.act_out + (long long)b * p.act_bs + pix : nullptr;
+            dptr[j] = p.dact_src ? p.dact_src + (long long)b * p.dact_bs + pix : nullptr;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float bias_v[16];          // this lane's 16 rows of the row tile: loaded together, branch-free
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            const bool use = p.bias != nullptr && !split && m < p.M;
+            const float* bp = use ? p.bias + m : p.in;          // always a valid address; value discarded when unused
+            bias_v[r] = use ? *bp : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float* o = const_cast<float*>(optr[j]);
+            if (o == nullptr) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                if (m < p.M) {
+                    float val = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+                    if (EPI && !split) {
+                        if (dptr[j]) val = roottanh_grad_f(dptr[j][(long long)m * plane], val);
+                        if (actp[j]) actp[j][(long long)m * plane] = roottanh_f(val);
+                    }
+                    o[(long long)m * plane] = val;
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private 4 MiB L2s), so
+// neighbouring tiles - which share a weight-panel slice (same m tile) or a gathered slice (same n tile) - would each
+// fetch it into a different L2.  Remap so that every XCD walks a contiguous chunk of the x-fastest tile order
+// (bijective for any grid size): the co-resident blocks of an XCD then share their operand slices through its L2.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int nwg = nx * ny * (int)gridDim.z;
+    const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    bx = swz % nx;
+    const int t = swz / nx;
+    by = t % ny;
+    bz = t / ny;
+}
+
+// Per-thread state of the implicit-GEMM gather.  The gathered element of (column n, row k = (c, t)) sits at
+//   in + [b(n) in_bs + iy0(n) W + ix0(n)]  +  [c H W + dy(t) W + dx(t)]
+// = a lane part (fixed for the whole K loop) + a wave-uniform part (from the offset table): exactly the
+// voffset + soffset of a buffer load, whose descriptor also does the zero padding - a lane whose tap falls outside the
+// input passes an out-of-range voffset and gets 0 back without touching memory.  Per element that leaves three vector
+// instructions (mask bit -> voffset select) instead of the ~9 of 64-bit address arithmetic + two selects.
+struct GatherCol {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_off;   // bytes
+    unsigned tapmask;    // bit t: tap t reads inside the input for this column (bit 31 is never set)
+};
+
+__device__ __forceinline__ GatherCol gather_setup(const IgParams& p, const IgPhase& ph, int n, int N) {
+    GatherCol g;
+    g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + ph.dmin), 0, (int)(p.in_bytes - 4 * ph.dmin), 0x00020000);
+    const bool n_ok = n < N;
+    const int nn = n_ok ? n : 0;
+    const int qhw = ph.QH * ph.QW;
+    const int b = nn / qhw, q = nn - b * qhw;
+    const int qy = q / ph.QW, qx = q - qy * ph.QW;
+    const int iy0 = qy * p.istride, ix0 = qx * p.istride;
+    g.lane_off = (unsigned)(4 * ((long long)b * p.in_bs + (long long)iy0 * p.W + ix0));
+    g.tapmask = 0;
+    if (n_ok) {
+        for (int t = 0; t < ph.T; ++t) {
+            const int th = (t * ph.tw_magic) >> 16, tw = t - th * ph.TW;
+            const bool ok = (unsigned)(iy0 + ph.dy0 + ph.dys * th) < (unsigned)p.H &&
+                            (unsigned)(ix0 + ph.dx0 + ph.dxs * tw) < (unsigned)p.W;
+            g.tapmask |= (ok ? 1u : 0u) << t;
+        }
+    }
+    return g;
+}
+
+// soff: table entry of row k (bytes, wave-uniform); tap: its tap index (wave-uniform; 31 = never valid)
+__device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsigned tap) {
+    const int m = ((int)(g.tapmask << (31u - tap))) >> 31;          // -1 when the tap is inside the input
+    const unsigned vo = (g.lane_off & (unsigned)m) | (0x80000000u & ~(unsigned)m);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rsrc, (int)vo, soff, 0));
+}
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, bool EPI>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     constexpr int BK = IG_BK;
     constexpr int BM = WGM * TM * 32;
@@ -285,40 +458,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
-    const int zphase = blockIdx.z / p.ksplit, zsplit = blockIdx.z - zphase * p.ksplit;
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
     const int N = p.B * ph.QH * ph.QW;
-    const int n0 = blockIdx.x * BN;
-    const int m0 = blockIdx.y * BM;
+    const int n0 = bx * BN;
+    const int m0 = by * BM;
     if (n0 >= N) return;   // phases can have different extents; uniform per block
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
-    const int T = ph.T;
 
     // ---- per-thread gather column (fixed for the whole K loop): base pointer and the set of taps inside the input
     const int ncol = tid % BN;
     const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform
-    const int n = n0 + ncol;
-    unsigned tapmask = 0;    // bit t: tap t reads inside the input for this column (bit 31 is never set)
-    const float* in_col = p.in;
-    {
-        const bool n_ok = n < N;
-        const int nn = n_ok ? n : 0;
-        const int qhw = ph.QH * ph.QW;
-        const int b = nn / qhw, q = nn - b * qhw;
-        const int qy = q / ph.QW, qx = q - qy * ph.QW;
-        const int iy0 = qy * p.istride, ix0 = qx * p.istride;
-        in_col += (long long)b * p.in_bs + (long long)iy0 * p.W + ix0;
-        if (n_ok) {
-            for (int t = 0; t < T; ++t) {
-                const int th = (t * ph.tw_magic) >> 16, tw = t - th * ph.TW;
-                const bool ok = (unsigned)(iy0 + ph.dy0 + ph.dys * th) < (unsigned)p.H &&
-                                (unsigned)(ix0 + ph.dx0 + ph.dxs * tw) < (unsigned)p.W;
-                tapmask |= (ok ? 1u : 0u) << t;
-            }
-        }
-    }
+    const GatherCol gc = gather_setup(p, ph, n0 + ncol, N);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -354,8 +509,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 
     float breg[KPT];
     float4 areg[A_PT];
-    unsigned bmask = 0;      // validity bits of breg[]; applied when the tile is written to LDS (the loads themselves
-                             // are unconditional: masked elements read element 0 of the column)
     auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
@@ -365,15 +518,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         const int ks = __builtin_amdgcn_readfirstlane(kidx);
         const i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + ks);                      // s_load_dwordx8
         const unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + ks);   // s_load_dwordx2
-        unsigned m = 0;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const unsigned tap = (unsigned)(taps >> (8 * j)) & 31u;
-            const bool valid = (tapmask >> tap) & 1u;
-            breg[j] = in_col[valid ? offs[j] : 0];
-            m |= (valid ? 1u : 0u) << j;
-        }
-        bmask = m;
+        for (int j = 0; j < KPT; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
         kidx += BK;
     };
     auto store_tiles = [&](int buf) {
@@ -387,7 +533,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = ((bmask >> j) & 1u) ? breg[j] : 0.0f;
+        for (int j = 0; j < KPT; ++j) Bs[buf][kgrp * KPT + j][ncol] = breg[j];
     };
 
     if (nsteps > 0) {
@@ -420,52 +566,150 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const long long plane = (long long)p.OH * p.OW;
-    const bool split = p.ksplit > 1;
-    const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
-    float col_scale[TN];           // 1/sigma of the column's group (the batch may stack several forwards)
+    igemm_epilogue<WGM, WGN, TM, TN, EPI>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// "bf16 x 6": the same GEMM with BOTH operands split into three bf16 pieces x = h + m + l (exact: 3 x 8 significant
+// bits cover fp32's 24) and the six products of combined order <= 2^-16 kept: h*h, h*m, m*h, m*m, h*l, l*h.  The
+// dropped m*l, l*m, l*l terms are O(2^-24) of the product - fp32-level accuracy (the results agree with the fp32
+// MFMA path to summation order) at 192 instead of 512 matrix-core cycles per 32x32x16 slice.  The weights are split once
+// per optimizer step (panel planes w3), the gathered activations while their tile is written to LDS.
+// LDS images are [piece][k / 8][column][8 bf16]: one ds_read_b128 per lane delivers an MFMA fragment (lane (r, h)
+// holds k = 8h .. 8h + 7 of row / column r), one ds_write_b128 per gathered fragment, conflict-free both ways.
+// ---------------------------------------------------------------------------------------------
+#define B6_BK 16
+
+template <int WGM, int WGN, int TM, int TN, bool EPI>
+__global__ void __launch_bounds__(256) conv_igemm_bx6_kernel(const IgParams p) {
+    constexpr int BK = B6_BK, KB = BK / 8;
+    constexpr int BM = WGM * TM * 32;
+    constexpr int BN = WGN * TN * 32;
+    static_assert(WGM * WGN == 4, "four waves");
+    static_assert(BN == 128 && KB * BN == 256, "one gathered fragment (k-block) per thread and stage");
+    static_assert(KB * BM <= 256, "at most one weight fragment per thread and stage");
+
+    __shared__ uint4 As[2][3][KB][BM];
+    __shared__ uint4 Bs[2][3][KB][BN];
+
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
+    const IgPhase& ph = p.ph[zphase];
+    const int N = p.B * ph.QH * ph.QW;
+    const int n0 = bx * BN;
+    const int m0 = by * BM;
+    if (n0 >= N) return;   // phases can have different extents; uniform per block
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    // ---- per-thread gather column (fixed for the whole K loop): base pointer and the set of taps inside the input
+    const int ncol = tid % BN;
+    const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform k-block of this thread's fragment
+    const GatherCol gc = gather_setup(p, ph, n0 + ncol, N);
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nj = n0 + (wn * TN + j) * 32 + lcol;
-        const int nn = nj < N ? nj : 0;
-        const int qhw = ph.QH * ph.QW;
-        const int b = nn / qhw, q = nn - b * qhw;
-        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
-        const int qy = q / ph.QW, qx = q - qy * ph.QW;
-        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
-        const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
-                               : p.out + (long long)b * p.out_bs + pix;
-        optr[j] = nj < N ? o : nullptr;
-    }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float bias_v[16];          // this lane's 16 rows of the row tile: loaded together, branch-free
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            const bool use = p.bias != nullptr && !split && m < p.M;
-            const float* bp = use ? p.bias + m : p.in;          // always a valid address; value discarded when unused
-            bias_v[r] = use ? *bp : 0.0f;
-        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- K range of this block (split-K)
+    const int total_steps = ph.Kpad / BK;
+    const int per_split = (total_steps + p.ksplit - 1) / p.ksplit;
+    const int step0 = zsplit * per_split;
+    int nsteps = total_steps - step0;
+    if (nsteps > per_split) nsteps = per_split;
+    if (nsteps < 0) nsteps = 0;
+
+    // weight fragment of this thread: chunk (k-block a_kb, column m0 + a_m) of the three pre-split planes
+    const bool a_thread = KB * BM == 256 || tid < KB * BM;
+    const int a_kb = a_thread ? tid / BM : 0, a_m = a_thread ? tid % BM : 0;
+    const bool a_ok = a_thread && (m0 + a_m) < ph.ld;
+    const uint4* ap = ph.w3 + (long long)(step0 * KB + a_kb) * ph.ld + (a_ok ? m0 + a_m : 0);
+    const long long a_step = (long long)KB * ph.ld, a_plane = ph.w3_plane;
+    int kidx = step0 * BK + kgrp * 8;                             // wave-uniform first table row of the next load
+
+    uint4 areg[3];
+    float breg[8];
+    auto issue_loads = [&]() {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float* o = const_cast<float*>(optr[j]);
-            if (o == nullptr) continue;
+        for (int q = 0; q < 3; ++q) areg[q] = ap[q * a_plane];
+        ap += a_step;
+        const int ks = __builtin_amdgcn_readfirstlane(kidx);
+        const i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + ks);                        // s_load_dwordx8
+        const unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + ks);   // s_load_dwordx2
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+        for (int j = 0; j < 8; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
+        kidx += BK;
+    };
+    auto store_tiles = [&](int buf) {
+        if (a_thread) {
+            const unsigned keep = a_ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                uint4 v = areg[q];
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                As[buf][q][a_kb][a_m] = v;
             }
         }
+        bf16x8 h, m, l;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = breg[j];
+        split3_bf16x8(v, h, m, l);
+        Bs[buf][0][kgrp][ncol] = *reinterpret_cast<uint4*>(&h);
+        Bs[buf][1][kgrp][ncol] = *reinterpret_cast<uint4*>(&m);
+        Bs[buf][2][kgrp][ncol] = *reinterpret_cast<uint4*>(&l);
+    };
+
+    if (nsteps > 0) {
+        issue_loads();
+        store_tiles(0);
     }
+    __syncthreads();
+    const int lrow = lane >> 5, lcol = lane & 31;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        issue_loads();                       // prefetch of step s + 1 (redundant but in bounds on the last iteration)
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][lrow][(wm * TM + i) * 32 + lcol]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][lrow][(wn * TN + j) * 32 + lcol]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    igemm_epilogue<WGM, WGN, TM, TN, EPI>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
 }
 
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 int scale_bg, int scale_stride, int B, int M, int plane,
-                                                                long long out_bs, long long slab_stride, int ksplit) {
+                                                                long long out_bs, long long slab_stride, int ksplit,
+                                                                float* __restrict__ act_out, long long act_bs,
+                                                                const float* __restrict__ dact_src, long long dact_bs) {
     const long long per_b = (long long)M * plane;
     const long long total = (long long)B * per_b;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -475,7 +719,9 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
         for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
         if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
         if (bias) acc += bias[(int)(r / plane)];
+        if (dact_src) acc = roottanh_grad_f(dact_src[b * dact_bs + r], acc);
         out[b * out_bs + r] = acc;
+        if (act_out) act_out[b * act_bs + r] = roottanh_f(acc);
     }
 }
 
@@ -533,10 +779,19 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     for (int m = 0; m < MT; ++m) {
         if (m < p.M) {
             const float bv = p.bias ? p.bias[m] : 0.0f;
-            if (PX == 2)
-                *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(fmaf(acc[m][0], sc, bv), fmaf(acc[m][PX - 1], sc, bv));
-            else
-                op[(long long)m * HW] = fmaf(acc[m][0], sc, bv);
+            float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
+            if (p.dact_src) {
+                const float* dp = p.dact_src + (long long)b * p.dact_bs + q + (long long)m * HW;
+                v0 = roottanh_grad_f(dp[0], v0);
+                if (PX == 2) v1 = roottanh_grad_f(dp[1], v1);
+            }
+            if (PX == 2) *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(v0, v1);
+            else op[(long long)m * HW] = v0;
+            if (p.act_out) {
+                float* ap = p.act_out + (long long)b * p.act_bs + q + (long long)m * HW;
+                ap[0] = roottanh_f(v0);
+                if (PX == 2) ap[1] = roottanh_f(v1);
+            }
         }
     }
 }
@@ -615,15 +870,35 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     if (p.ksplit > min_kpad / IG_BK) p.ksplit = min_kpad / IG_BK;
     if (p.ksplit < 1) p.ksplit = 1;
     dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
-    if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
-    else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
-    else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
-    else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    const bool epi = (p.act_out || p.dact_src) && p.ksplit == 1;       // with split-K the slab reduction applies them
+    if (!path_disabled("bx6")) {
+        if (epi) {
+            if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
+            else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, true><<<grid, 256, 0, st>>>(p);
+            else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, true><<<grid, 256, 0, st>>>(p);
+            else conv_igemm_bx6_kernel<1, 4, 1, 1, true><<<grid, 256, 0, st>>>(p);
+        } else {
+            if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(p);
+            else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, false><<<grid, 256, 0, st>>>(p);
+            else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, false><<<grid, 256, 0, st>>>(p);
+            else conv_igemm_bx6_kernel<1, 4, 1, 1, false><<<grid, 256, 0, st>>>(p);
+        }
+    } else if (epi) {
+        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, true><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, true><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_kernel<1, 4, 1, 1, true><<<grid, 256, 0, st>>>(p);
+    } else {
+        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, false><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, false><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_kernel<1, 4, 1, 1, false><<<grid, 256, 0, st>>>(p);
+    }
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
         igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
-                                                                         p.slab_stride, p.ksplit);
+                                                                         p.slab_stride, p.ksplit, p.act_out, p.act_bs, p.dact_src, p.dact_bs);
         LOCATE_LAUNCH_CHECK(who);
     }
     return LOCATE_OK;
@@ -633,6 +908,13 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
 static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const char* who) {
     const PackJob j = make_pack_job(b, nphase);
     pack_job_kernel<<<j.gx * j.gy, 256, 0, st>>>(j);
+    LOCATE_LAUNCH_CHECK(who);
+    int64_t big = 1;
+    for (int i = 0; i < nphase; ++i) {
+        const int64_t t = (int64_t)(b.ph[i].rows / 8) * b.ph[i].ld;
+        if (t > big) big = t;
+    }
+    pack_split_kernel<<<dim3(stream_grid(big, 256), nphase), 256, 0, st>>>(j);
     LOCATE_LAUNCH_CHECK(who);
     return LOCATE_OK;
 }
@@ -662,10 +944,24 @@ static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int*
     *T = *k0 < K ? (K - *k0 + s - 1) / s : 0;
 }
 
+// most negative displacement dy*W + dx over the taps of a phase (0 if none is negative)
+static int tap_dmin(const PackArgs& a) {
+    int best = 0;
+    for (int th = 0; th < a.TH; ++th)
+        for (int tw = 0; tw < a.TW; ++tw) {
+            const int d = (a.dy0 + a.dys * th) * a.gW + a.dx0 + a.dxs * tw;
+            if (d < best) best = d;
+        }
+    return best;
+}
+
 static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
     ph.wp = panel_base;
     ph.koff = reinterpret_cast<const int*>(panel_base + (size_t)pa.rows * pa.ld);
     ph.ktap = reinterpret_cast<const unsigned char*>(ph.koff + pa.rows);
+    ph.w3 = reinterpret_cast<const uint4*>(panel_base + panel_split_offset(pa.rows, pa.ld));
+    ph.w3_plane = (long long)(pa.rows / 8) * pa.ld;
+    ph.dmin = pa.dmin;
     ph.K = pa.K; ph.Kpad = pa.rows - IG_TAIL; ph.ld = pa.ld;
     ph.TW = pa.TW > 0 ? pa.TW : 1; ph.tw_magic = (65536 + ph.TW - 1) / ph.TW;
     ph.dy0 = pa.dy0; ph.dys = pa.dys; ph.dx0 = pa.dx0; ph.dxs = pa.dxs;
@@ -689,6 +985,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
         pa.K = g.C * g.KH * g.KW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
         pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = -g.pad_h; pa.dys = 1; pa.dx0 = -g.pad_w; pa.dxs = 1;
+        pa.dmin = tap_dmin(pa);
         batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
@@ -714,6 +1011,7 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 pa.kh0 = kh0; pa.kw0 = kw0; pa.s = g.stride; pa.TH = TH; pa.TW = TW;
                 pa.K = g.M * TH * TW; pa.rows = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.C, 32);
                 pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
+                pa.dmin = tap_dmin(pa);
                 batch.ph[p.nphase - 1] = pa;
                 phase_finish(ph, pa, pa.out);
                 ph.T = TH * TW;
@@ -775,18 +1073,26 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
     LOCATE_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "locate_conv_pack_panels: bad arguments");
     pack_jobs_kernel<<<total_blocks, 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     LOCATE_LAUNCH_CHECK("locate_conv_pack_panels");
+    pack_split_jobs_kernel<<<dim3(PACK_SPLIT_BLOCKS, n_jobs, 4), 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs));
+    LOCATE_LAUNCH_CHECK("locate_conv_pack_panels(split)");
     return LOCATE_OK;
 }
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
-                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st,
-                     const char* who) {
+                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* act_out,
+                     int64_t act_bs, const float* dact_src, int64_t dact_bs, float* ws, hipStream_t st, const char* who) {
     IgParams p;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
     p.scale_bg = scale_bg; p.scale_stride = scale_stride;
+    p.act_out = act_out; p.act_bs = act_bs; p.dact_src = dact_src; p.dact_bs = dact_bs;
+    {
+        const long long extent = 4ll * ((long long)(p.B - 1) * in_bs + (long long)p.C * p.H * p.W);
+        LOCATE_REQUIRE(in_bs >= 0 && extent > 0 && extent < (1ll << 31) - (1 << 20), "%s: gathered tensor of %lld bytes exceeds the 2 GiB a buffer descriptor addresses", who, extent);
+        p.in_bytes = (unsigned)extent;
+    }
     LOCATE_REQUIRE(scale_bg >= 0 && (scale_bg == 0 || g.B % scale_bg == 0), "%s: batch %d is not a multiple of the scale group %d", who, g.B, scale_bg);
     LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
     return launch_igemm(p, nmax, ws, st, who);
@@ -807,14 +1113,18 @@ LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) { return ig
 // x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
 // scale (nullable): scale_group_batch = 0 -> one device scalar; > 0 -> batch element b uses
 // scale[(b / scale_group_batch) * scale_stride] (several forwards stacked along the batch, each with its own sigma).
+// Fused epilogue (both nullable): act_out [B, M, OH, OW] (batch stride act_bs) also receives RootTanh(y);
+// dact_src (batch stride dact_bs): y is multiplied by RootTanh'(dact_src) - the backward of an activation that
+// precedes the layer whose data gradient this call computes (libs/conv.py:22-24, libs/activation.py:22-36).
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               void* workspace, void* stream) {
+                               float* act_out, int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace,
+                               void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
-    return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
-                     as_stream(stream), "locate_conv_fwd");
+    return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, act_out, act_bs, dact_src,
+                     dact_bs, static_cast<float*>(workspace), as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
@@ -822,12 +1132,13 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 void* workspace, void* stream) {
+                                 float* act_out, int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace,
+                                 void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
-    return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
-                     static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
+    return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs, act_out, act_bs, dact_src,
+                     dact_bs, static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------

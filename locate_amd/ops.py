@@ -30,6 +30,12 @@ def _c(t, what="tensor"):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def path_disabled(name):
+    """Debugging knob for A/B timing: LOCATE_DISABLE=pair,pointwise,... switches optional fused paths off."""
+    import os
+    return name in os.environ.get("LOCATE_DISABLE", "").split(",")
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -514,131 +520,244 @@ def sn_power_iteration(w_bar, u, v):
     return sigma, wv
 
 
+# ---- shared pieces of the spectral-normalised contractions ------------------------------------------------------
+def _sigma_args(sigma, batch):
+    """sigma: {sigma, 1/sigma}, or [n, 2] for n stacked calls (one power iteration each, in call order).
+    Returns (groups, scale_group_batch, scale_stride, pointer tensor to the first 1/sigma)."""
+    groups = sigma.shape[0] if sigma.dim() == 2 else 1
+    if groups == 1:
+        return 1, 0, 0, sigma.reshape(-1)[1:]
+    if batch % groups or groups > 4 or sigma.stride(1) != 1:
+        raise ValueError("conv: batch %d cannot stack %d calls" % (batch, groups))
+    return groups, batch // groups, sigma.stride(0), sigma[0, 1:]
+
+
+def _fuse_act_max():
+    """Largest tensor (elements) whose RootTanh is fused into the producing conv's epilogue.  Small layers are
+    launch-bound (one launch less wins); on big ones the serial per-lane transcendental tail of the MFMA kernel costs
+    more than a separate full-bandwidth element-wise pass (measured: fusing everywhere was 0.3 ms/step slower)."""
+    import os
+    return int(os.environ.get("LOCATE_FUSE_ACT_MAX", 1 << 19))
+
+
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, want_act=False):
+    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`); with `want_act` also
+    RootTanh(y) - from the same launch for small tensors.  Returns (y, act or None)."""
+    L = lib()
+    st = _stream()
+    y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    act = torch.empty_like(y) if want_act else None
+    if want_act and y.numel() > _fuse_act_max():
+        y, _ = _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape)
+        check(L.locate_roottanh_fwd(_p(y), _p(act), y.numel(), st), "locate_roottanh_fwd")
+        return y, act
+    _, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
+    abs_ = _bs(act) if want_act else 0
+    if spec.kind == "conv":
+        ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
+        check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                _bs(y), _p(act), abs_, None, 0, _p(ws), st), "locate_conv_fwd")
+    else:
+        ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
+        check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                  _bs(y), _p(act), abs_, None, 0, _p(ws), st), "locate_conv_dgrad")
+    return y, act
+
+
+def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, dact_src=None):
+    """Gradient w.r.t. the layer input; with `dact_src` (the pre-activation tensor the input was RootTanh of) the result
+    is already multiplied by RootTanh'(dact_src), i.e. it is the gradient w.r.t. that pre-activation."""
+    L = lib()
+    st = _stream()
+    if dact_src is not None and dact_src.numel() > _fuse_act_max():
+        g = _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma)
+        check(L.locate_roottanh_bwd(_p(dact_src), _p(g), _p(g), g.numel(), st), "locate_roottanh_bwd")     # in place
+        return g
+    gx = torch.empty_like(x_like)
+    _, sbg, sst, inv_sigma = _sigma_args(sigma, gy.shape[0])
+    dbs = _bs(dact_src) if dact_src is not None else 0
+    if spec.kind == "conv":
+        ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), gy.device)
+        check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, None, _p(gx),
+                                  _bs(gx), None, 0, _p(dact_src), dbs, _p(ws), st), "locate_conv_dgrad")
+    else:
+        ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), gy.device)
+        check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, None, _p(gx),
+                                _bs(gx), None, 0, _p(dact_src), dbs, _p(ws), st), "locate_conv_fwd")
+    return gx
+
+
+def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, garr, need_u, need_v):
+    """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
+    (_register_pending_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side)."""
+    L = lib()
+    st = _stream()
+    groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
+    gw = torch.empty_like(w)
+    ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
+    xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
+    h = w.shape[0]
+    wd = w.numel() // h
+    u, v = u_param.detach(), v_param.detach()
+    gu = torch.empty_like(u) if need_u else None
+    if groups > 1:
+        # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
+        # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
+        check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), None, _p(inv_sigma), sbg, sst, None,
+                                  _p(ws), st), "locate_conv_wgrad")
+        dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
+        gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
+        Bn, Mn = gy.shape[0], gy.shape[1]
+        check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bias), groups, Bn // groups, Mn,
+                                             gy.numel() // (Bn * Mn), _p(sigma), sigma.stride(0), _p(u), _p(v), _p(wv),
+                                             wv.stride(0), _p(gw), _p(gu), _p(dsig), h, wd, _p(gws), st),
+              "locate_sn_weight_bwd_grouped")
+        return gw, gu
+    # one pass: gw = G / sigma_k (G = gradient w.r.t. the normalised weight) plus the partial sums of <G, W_bar>;
+    # then the rank-1 spectral-norm correction in place
+    npart = L.locate_conv_wgrad_partials(garr)
+    partial = torch.empty(npart, dtype=torch.float64, device=x.device)
+    check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), 0, 0, _p(partial),
+                              _p(ws), st), "locate_conv_wgrad")
+    dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
+    check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
+          "locate_sn_weight_bwd")
+    return gw, gu
+
+
+def _bias_grad(gy):
+    Bn, Cn = gy.shape[0], gy.shape[1]
+    gb = torch.empty(Cn, dtype=torch.float32, device=gy.device)
+    check(lib().locate_channel_sum(_p(gy), _p(gb), Bn, Cn, gy.numel() // (Bn * Cn), _bs(gy), _stream()), "locate_channel_sum")
+    return gb
+
+
+def _dense(t, what):
+    _chk(t, what)
+    return t if _dense_planes(t) else t.contiguous()
+
+
 class SNConvFn(torch.autograd.Function):
     """y = conv(x, W_bar / sigma) + bias for Conv2d / ConvTranspose2d semantics (Conv1d(k=1), Linear and the
     (S x 1)/(1 x S) feature-attention convs are reshaped to 1x1 convs by the caller).  sigma / wv are the
     results of THIS forward's power iteration; u, v are inputs only so that their gradients can be returned
     (the reference's main.py:172 makes them trainable) - they are read at backward time, i.e. with the values
-    left by the latest forward, exactly like the reference's autograd does."""
+    left by the latest forward, exactly like the reference's autograd does.
+    with_act: returns (y, RootTanh(y)) from the same launch (libs/linear.py:8-11)."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec):
-        L = lib()
-        st = _stream()
-        _chk(x, "conv input")
-        if not _dense_planes(x):
-            x = x.contiguous()
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, with_act=False):
+        x = _dense(x, "conv input")
         w = _c(w_bar, "weight_bar")
         owner = _panel_owner(w_bar)
         geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
         garr = _geom(geom)
-        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-        # sigma: {sigma, 1/sigma}, or [n, 2] for n stacked calls (one power iteration each, in call order)
-        groups = sigma.shape[0] if sigma.dim() == 2 else 1
-        if groups > 1 and (x.shape[0] % groups or groups > 4 or sigma.stride(1) != 1):
-            raise ValueError("conv: batch %d cannot stack %d calls" % (x.shape[0], groups))
-        sbg = x.shape[0] // groups if groups > 1 else 0
-        sst = sigma.stride(0) if groups > 1 else 0
-        inv_sigma = sigma.reshape(-1)[1:] if groups == 1 else sigma[0, 1:]
         b = _c(bias) if bias is not None else None
-        if spec.kind == "conv":
-            ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(b), _p(y),
-                                    _bs(y), _p(ws), st), "locate_conv_fwd")
-        else:
-            ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(b), _p(y),
-                                      _bs(y), _p(ws), st), "locate_conv_dgrad")
-        ctx.groups = groups
-        if groups > 1:
-            ctx.save_for_backward(x, w, sigma, wv, y, b)     # <G_k, W_bar> is taken on the activation side (needs y)
+        y, act = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, want_act=with_act)
+        groups = sigma.shape[0] if sigma.dim() == 2 else 1
+        ctx.groups, ctx.with_act = groups, with_act
+        if groups > 1 or with_act:
+            ctx.save_for_backward(x, w, sigma, wv, y, b)     # stacked: <G_k, W_bar> is taken on the activation side
         else:
             ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.owner = owner
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
+        if with_act:
+            return y, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, gact=None):
+        if ctx.groups > 1 or ctx.with_act:
+            x, w, sigma, wv, y, bsaved = ctx.saved_tensors
+        else:
+            x, w, sigma, wv = ctx.saved_tensors
+            y = bsaved = None
+        spec, garr = ctx.spec, _geom(ctx.geom)
+        if ctx.with_act:
+            # two consumers of y: the direct one (gy) and RootTanh (gact)
+            if gact is None:
+                gy = _dense(gy, "conv output gradient")
+            elif gy is None:
+                gy = RootTanhFn_backward(y, gact)
+            else:
+                g = torch.empty_like(y)
+                check(lib().locate_roottanh_bwd_add(_p(y), _p(_c(gact)), _p(_c(gy)), _p(g), y.numel(), _stream()),
+                      "locate_roottanh_bwd_add")
+                gy = g
+        else:
+            gy = _dense(gy, "conv output gradient")
+        need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
+        gx = gw = gu = gb = None
+        if need_x:
+            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma)
+        if need_w or need_u or need_v:
+            gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, garr, need_u, need_v)
+            if not need_w:
+                gw = None
+        if ctx.has_bias and need_b:
+            gb = _bias_grad(gy)
+        # gv is assigned to v.grad by _finalize_pending_dv at the end of this backward pass
+        return gx, gw, gu, None, gb, None, None, None, None
+
+
+def RootTanhFn_backward(x, g):
+    gx = torch.empty_like(x)
+    check(lib().locate_roottanh_bwd(_p(x), _p(_c(g)), _p(gx), x.numel(), _stream()), "locate_roottanh_bwd")
+    return gx
+
+
+class ActivatedPairFn(torch.autograd.Function):
+    """y = conv_1(RootTanh(conv_0(h))) - the two spectral-normalised convs of one stage (libs/conv.py:14-24) with the
+    activation between them fused into conv_0's epilogue (forward) and into conv_1's data-gradient epilogue
+    (backward): no separate RootTanh launches, no extra pass over the stage's widest tensor."""
+
+    @staticmethod
+    def forward(ctx, h, w0_bar, u0, v0, sig0, wv0, spec0, w1_bar, u1, v1, sig1, wv1, spec1):
+        h = _dense(h, "conv input")
+        w0, w1 = _c(w0_bar, "weight_bar"), _c(w1_bar, "weight_bar")
+        own0, own1 = _panel_owner(w0_bar), _panel_owner(w1_bar)
+        geom0, shape0 = spec0.geometry(tuple(h.shape), tuple(w0.shape))
+        c0, a = _conv_apply(h, w0, own0, spec0, geom0, _geom(geom0), sig0, None, shape0, want_act=True)
+        geom1, shape1 = spec1.geometry(tuple(a.shape), tuple(w1.shape))
+        y, _ = _conv_apply(a, w1, own1, spec1, geom1, _geom(geom1), sig1, None, shape1)
+        ctx.groups = sig0.shape[0] if sig0.dim() == 2 else 1
+        ctx.save_for_backward(h, w0, sig0, wv0, c0, a, w1, sig1, wv1, y if ctx.groups > 1 else None)
+        ctx.params = (u0, v0, u1, v1)
+        ctx.meta = (own0, geom0, spec0, own1, geom1, spec1)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        L = lib()
-        st = _stream()
-        groups = ctx.groups
-        if groups > 1:
-            x, w, sigma, wv, y, bsaved = ctx.saved_tensors
-        else:
-            x, w, sigma, wv = ctx.saved_tensors
-        spec, garr = ctx.spec, _geom(ctx.geom)
-        _chk(gy, "conv output gradient")
-        if not _dense_planes(gy):
-            gy = gy.contiguous()
-        need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
-        gx = gw = gu = gv = gb = None
-        sbg = x.shape[0] // groups if groups > 1 else 0
-        sst = sigma.stride(0) if groups > 1 else 0
-        inv_sigma = sigma.reshape(-1)[1:] if groups == 1 else sigma[0, 1:]
-        if need_x:
-            gx = torch.empty_like(x)
-            if spec.kind == "conv":
-                ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-                check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 1)), _p(inv_sigma), sbg, sst,
-                                          None, _p(gx), _bs(gx), _p(ws), st), "locate_conv_dgrad")
-            else:
-                ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-                check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(ctx.owner, w, ctx.geom, garr, 0)), _p(inv_sigma), sbg, sst,
-                                        None, _p(gx), _bs(gx), _p(ws), st), "locate_conv_fwd")
-        if groups > 1 and (need_w or need_u or need_v):
-            # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
-            # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
-            gw = torch.empty_like(w)
-            ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
-            xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)
-            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), None, _p(inv_sigma), sbg, sst, None,
-                                      _p(ws), st), "locate_conv_wgrad")
-            h = w.shape[0]
-            wd = w.numel() // h
-            u, v = ctx.u.detach(), ctx.v.detach()
-            gu = torch.empty_like(u) if need_u else None
-            dsig = _register_pending_dv(ctx.v, ctx.u, w, h, wd) if need_v else None
-            gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
-            Bn, Mn = gy.shape[0], gy.shape[1]
-            check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bsaved), groups, Bn // groups, Mn,
-                                                 gy.numel() // (Bn * Mn), _p(sigma), sigma.stride(0), _p(u), _p(v), _p(wv),
-                                                 wv.stride(0), _p(gw), _p(gu), _p(dsig), h, wd, _p(gws), st),
-                  "locate_sn_weight_bwd_grouped")
-            if not need_w:
-                gw = None
-        elif need_w or need_u or need_v:
-            # one pass: gw = G / sigma_k (G = gradient w.r.t. the normalised weight) plus the partial sums of <G, W_bar>;
-            # then the rank-1 spectral-norm correction in place
-            gw = torch.empty_like(w)
-            npart = L.locate_conv_wgrad_partials(garr)
-            partial = torch.empty(npart, dtype=torch.float64, device=x.device)
-            ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
-            xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
-            check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), 0, 0, _p(partial),
-                                      _p(ws), st), "locate_conv_wgrad")
-            h = w.shape[0]
-            wd = w.numel() // h
-            u, v = ctx.u.detach(), ctx.v.detach()
-            gu = torch.empty_like(u) if need_u else None
-            dsig = _register_pending_dv(ctx.v, ctx.u, w, h, wd) if need_v else None
-            check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
-                  "locate_sn_weight_bwd")
-            gv = None      # assigned to v.grad by _finalize_pending_dv at the end of this backward pass
-            if not need_w:
-                gw = None
-        if ctx.has_bias and need_b:
-            Bn, Cn = gy.shape[0], gy.shape[1]
-            gb = torch.empty(Cn, dtype=torch.float32, device=gy.device)
-            check(L.locate_channel_sum(_p(gy), _p(gb), Bn, Cn, gy.numel() // (Bn * Cn), _bs(gy), st), "locate_channel_sum")
-        return gx, gw, gu, gv, gb, None, None, None
+        h, w0, sig0, wv0, c0, a, w1, sig1, wv1, y = ctx.saved_tensors
+        u0, v0, u1, v1 = ctx.params
+        own0, geom0, spec0, own1, geom1, spec1 = ctx.meta
+        garr0, garr1 = _geom(geom0), _geom(geom1)
+        gy = _dense(gy, "conv output gradient")
+        nd = ctx.needs_input_grad
+        need_h, need_w0, need_u0, need_v0 = nd[0], nd[1], nd[2], nd[3]
+        need_w1, need_u1, need_v1 = nd[7], nd[8], nd[9]
+        gh = gw0 = gu0 = gw1 = gu1 = None
+        if need_w1 or need_u1 or need_v1:
+            gw1, gu1 = _conv_weight_grad(a, gy, y, None, w1, u1, v1, sig1, wv1, spec1, garr1, need_u1, need_v1)
+            if not need_w1:
+                gw1 = None
+        if need_h or need_w0 or need_u0 or need_v0:
+            g_c0 = _conv_input_grad(gy, a, w1, own1, spec1, geom1, garr1, sig1, dact_src=c0)   # incl. RootTanh'(c0)
+            if need_w0 or need_u0 or need_v0:
+                gw0, gu0 = _conv_weight_grad(h, g_c0, c0, None, w0, u0, v0, sig0, wv0, spec0, garr0, need_u0, need_v0)
+                if not need_w0:
+                    gw0 = None
+            if need_h:
+                gh = _conv_input_grad(g_c0, h, w0, own0, spec0, geom0, garr0, sig0)
+        return gh, gw0, gu0, None, None, None, None, gw1, gu1, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, with_act=False):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
-    batched update is supplied."""
+    batched update is supplied.  with_act: returns (y, RootTanh(y))."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, with_act)

@@ -30,9 +30,23 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / denom
 
 
+_REPORT = []
+
+
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
+    if os.environ.get("LOCATE_TOL_REPORT"):          # survey mode: collect the error/tolerance ratios instead of failing
+        _REPORT.append((e / tol, e, tol, what))
+        return
     assert e <= tol, "%s: normalised max error %.3e > %.1e" % (what, e, tol)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _REPORT:
+        worst = sorted(_REPORT, reverse=True)[:25]
+        print("\nworst error / tolerance ratios:")
+        for r, e, tol, what in worst:
+            print("  %7.2fx  err %.3e  tol %.1e  %s" % (r, e, tol, what))
 
 
 @pytest.fixture(scope="session")
