@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 #define B6_BK 16
 
 template <int WGM, int WGN, int TM, int TN, bool EPI>
-__global__ void __launch_bounds__(256) conv_igemm_bx6_kernel(const IgParams p) {
+__global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p) {
     constexpr int BK = B6_BK, KB = BK / 8;
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
@@ -1153,6 +1153,7 @@ struct WgParams {
     const float* gy;    // dense activation    [B, M, OH, OW]
     float* slab;        // [nsplit][M * R]
     long long x_bs, gy_bs;
+    unsigned x_bytes;   // extent of the x view in bytes (buffer descriptor bound of the bf16 path)
     int B, C, H, W, M, OH, OW, KH, KW, stride, pad_h, pad_w;
     int R;              // C * KH * KW
     int N;              // B * OH * OW
@@ -1180,6 +1181,54 @@ static void fastdiv_make(unsigned d, unsigned* mul, int* s1, int* s2) {
     while ((1ull << l) < d) ++l;
     *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
     *s1 = 1; *s2 = l - 1;
+}
+
+// Shared epilogue of the weight-gradient kernels.
+template <int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void wgrad_epilogue(const WgParams& p, f32x16 (&acc)[TM][TN], int r0, int m0, int wm, int wn, int lane,
+                                               int wid, int tid) {
+    const int lrow = lane >> 5, lcol = lane & 31;
+    // epilogue.  With a single split the result is final: scale by 1/sigma, write the gradient in the weight's own
+    // layout and reduce this block's share of <G, W_bar> (spectral-norm backward needs it) - no slab round trip.
+    __shared__ double red[4];
+    const bool direct = p.direct_out != nullptr;
+    float* dst = direct ? p.direct_out : p.slab + (long long)blockIdx.z * p.M * p.R;
+    const float sc = (direct && p.inv_scale && p.gscale_bg == 0) ? p.inv_scale[0] : 1.0f;
+    double dot = 0.0;
+    const bool want_dot = direct && p.w_ref != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = r0 + (wn * TN + j) * 32 + lcol;
+        const bool r_ok = r < p.R;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // this lane's 16 rows of the 32x32 tile: W_bar values first (branch-free, all loads in flight), then the
+            // products in fp32 per tile and the running sum in fp64
+            float wref[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
+                const bool ok = want_dot && r_ok && m < p.M;
+                const float* wp_ = ok ? p.w_ref + (long long)m * p.R + r : p.gy;      // always a mapped address
+                wref[e] = ok ? *wp_ : 0.0f;
+            }
+            float part = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
+                const float v = acc[i][j][e];
+                part = fmaf(v, wref[e], part);
+                if (r_ok && m < p.M) dst[(long long)m * p.R + r] = v * sc;
+            }
+            dot += (double)part;
+        }
+    }
+    if (direct && p.partial) {
+        dot = wave_sum_d(dot);
+        if (lane == 0) red[wid] = dot;
+        __syncthreads();
+        if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
 }
 
 template <int WGM, int WGN, int TM, int TN>
@@ -1313,47 +1362,176 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         __syncthreads();
     }
 
-    // epilogue.  With a single split the result is final: scale by 1/sigma, write the gradient in the weight's own
-    // layout and reduce this block's share of <G, W_bar> (spectral-norm backward needs it) - no slab round trip.
-    __shared__ double red[4];
-    const bool direct = p.direct_out != nullptr;
-    float* dst = direct ? p.direct_out : p.slab + (long long)blockIdx.z * p.M * p.R;
-    const float sc = (direct && p.inv_scale && p.gscale_bg == 0) ? p.inv_scale[0] : 1.0f;
-    double dot = 0.0;
-    const bool want_dot = direct && p.w_ref != nullptr;
+    wgrad_epilogue<WGM, WGN, TM, TN>(p, acc, r0, m0, wm, wn, lane, wid, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The weight gradient on the bf16 matrix cores with exact three-way splits (see conv_igemm_bx6_kernel).  The reduction
+// index n = (b, oh, ow) is the MFMA's k: every thread loads PAIRS of adjacent n (coalesced along n), splits them and
+// writes the packed bf16 pairs to LDS images [piece][row][n] (n contiguous, 48-byte row pitch: conflict-free
+// ds_read_b128 fragments of 8 consecutive n).  Needs even OH*OW and OW (a pair never straddles an image or a row).
+// ---------------------------------------------------------------------------------------------
+#define WB_BK 16                      // reduction elements per stage = one MFMA k
+#define WB_PITCH 12                   // dwords per LDS row: 8 (16 bf16) + 4 padding
+
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 hh, mm, ll;
+    hh[0] = (__bf16)v0; hh[1] = (__bf16)v1;
+    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
+    mm[0] = (__bf16)r0; mm[1] = (__bf16)r1;
+    ll[0] = (__bf16)(r0 - (float)mm[0]); ll[1] = (__bf16)(r1 - (float)mm[1]);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_bx6_kernel(const WgParams p) {
+    constexpr int BM = WGM * TM * 32;
+    constexpr int BR = WGN * TN * 32;
+    constexpr int G_PT = BM / 32;          // row groups per thread: rows sub + 32 i
+    constexpr int X_PT = BR / 32;
+    static_assert(WGM * WGN == 4, "four waves");
+
+    __shared__ unsigned Gs[2][3][BM][WB_PITCH];
+    __shared__ unsigned Xs[2][3][BR][WB_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int r0 = blockIdx.x * BR, m0 = blockIdx.y * BM;
+    const int taps = p.KH * p.KW;
+    const int np = tid & 7, sub = tid >> 3;      // pair index inside the stage (n = nb + 2 np), row/column subgroup 0..31
+    const int Q = p.OH * p.OW;
+
+    // per-thread invariants of the gathered operand: this thread always loads the same X_PT im2col columns
+    int xoff[X_PT], xdy[X_PT], xdx[X_PT];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int r = r0 + (wn * TN + j) * 32 + lcol;
-        const bool r_ok = r < p.R;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // this lane's 16 rows of the 32x32 tile: W_bar values first (branch-free, all loads in flight), then the
-            // products in fp32 per tile and the running sum in fp64
-            float wref[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
-                const bool ok = want_dot && r_ok && m < p.M;
-                const float* wp_ = ok ? p.w_ref + (long long)m * p.R + r : p.gy;      // always a mapped address
-                wref[e] = ok ? *wp_ : 0.0f;
-            }
-            float part = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
-                const float v = acc[i][j][e];
-                part = fmaf(v, wref[e], part);
-                if (r_ok && m < p.M) dst[(long long)m * p.R + r] = v * sc;
-            }
-            dot += (double)part;
+    for (int i = 0; i < X_PT; ++i) {
+        const int r = r0 + sub + 32 * i;
+        if (r < p.R) {
+            const int c = r / taps, t = r - c * taps;
+            const int kh = t / p.KW, kw = t - kh * p.KW;
+            xdy[i] = kh - p.pad_h;
+            xdx[i] = kw - p.pad_w;
+            xoff[i] = 4 * (c * p.H * p.W + xdy[i] * p.W + xdx[i]);
+        } else {
+            xdy[i] = -(1 << 20);               // never inside the input
+            xdx[i] = 0;
+            xoff[i] = 0;
         }
     }
-    if (direct && p.partial) {
-        dot = wave_sum_d(dot);
-        if (lane == 0) red[wid] = dot;
-        __syncthreads();
-        if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_begin = blockIdx.z * p.chunk;
+    int n_end = n_begin + p.chunk;
+    if (n_end > p.N) n_end = p.N;
+
+    // group scales (at most 4 groups) live in registers; gsc = the scale of the pairs currently held in greg[]
+    float gs0 = 1.0f, gs1 = 1.0f, gs2 = 1.0f, gs3 = 1.0f, gsc = 1.0f;
+    if (p.gscale_bg > 0) {
+        const int ng = p.B / p.gscale_bg;
+        gs0 = p.inv_scale[0];
+        gs1 = ng > 1 ? p.inv_scale[p.gscale_stride] : 1.0f;
+        gs2 = ng > 2 ? p.inv_scale[2 * p.gscale_stride] : 1.0f;
+        gs3 = ng > 3 ? p.inv_scale[3 * p.gscale_stride] : 1.0f;
     }
+
+    float2 greg[G_PT], xreg[X_PT];
+    auto load_tiles = [&](int nb) {
+        const int n = nb + 2 * np;                 // even; n + 1 is in the same image and output row
+        const bool ok = n < n_end;                 // n_end is even as well
+        const int nn = ok ? n : 0;
+        const int b = fastdiv(nn, p.q_mul, p.q_s1, p.q_s2), q = nn - b * Q;
+        const int oh = fastdiv(q, p.ow_mul, p.ow_s1, p.ow_s2), ow = q - oh * p.OW;
+        const float* gp = p.gy + (long long)b * p.gy_bs + q;
+        if (p.gscale_bg > 0) {
+            const int grp = b / p.gscale_bg;
+            gsc = grp == 0 ? gs0 : grp == 1 ? gs1 : grp == 2 ? gs2 : gs3;
+        }
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int m = m0 + sub + 32 * i;
+            const bool v = ok && m < p.M;
+            const float2 t = *reinterpret_cast<const float2*>(gp + (v ? (long long)m * Q : 0));
+            greg[i] = v ? t : make_float2(0.0f, 0.0f);
+        }
+        const int iy0 = oh * p.stride, ix0 = ow * p.stride;
+        const unsigned base = (unsigned)(4 * ((long long)b * p.x_bs + (long long)iy0 * p.W + ix0));
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) {
+            const bool vy = ok && (unsigned)(iy0 + xdy[i]) < (unsigned)p.H;
+            const bool v0 = vy && (unsigned)(ix0 + xdx[i]) < (unsigned)p.W;
+            const bool v1 = vy && (unsigned)(ix0 + p.stride + xdx[i]) < (unsigned)p.W;
+            const unsigned o = base + (unsigned)xoff[i];
+            // an out-of-range voffset makes the buffer load return 0 without touching memory (zero padding)
+            xreg[i].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(v0 ? o : 0x80000000u), 0, 0));
+            xreg[i].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(v1 ? o + 4u * (unsigned)p.stride : 0x80000000u), 0, 0));
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            unsigned h, m, l;
+            split3_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
+            Gs[buf][0][sub + 32 * i][np] = h;
+            Gs[buf][1][sub + 32 * i][np] = m;
+            Gs[buf][2][sub + 32 * i][np] = l;
+        }
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) {
+            unsigned h, m, l;
+            split3_pair(xreg[i].x, xreg[i].y, h, m, l);
+            Xs[buf][0][sub + 32 * i][np] = h;
+            Xs[buf][1][sub + 32 * i][np] = m;
+            Xs[buf][2][sub + 32 * i][np] = l;
+        }
+    };
+
+    const int nsteps = (n_end - n_begin + WB_BK - 1) / WB_BK;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    if (nsteps > 0) {
+        load_tiles(n_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        load_tiles(n_begin + (s + 1) * WB_BK);       // beyond n_end: every lane masked, nothing is read
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][lrow * 4]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][lrow * 4]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    wgrad_epilogue<WGM, WGN, TM, TN>(p, acc, r0, m0, wm, wn, lane, wid, tid);
 }
 
 // out = (sum_z slab[z]) * inv_scale;  partial[block] = this block's share of <sum_z slab[z], w_ref>.
@@ -1467,7 +1645,17 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     p.inv_scale = (direct || grouped) ? inv_scale : nullptr;
     p.partial = direct ? inner_partial : nullptr;
     dim3 grid((p.R + 127) / 128, (g.M + bm - 1) / bm, nsplit);
-    if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+    const long long x_extent = 4ll * ((long long)(g.B - 1) * x_bs + (long long)g.C * g.H * g.W);
+    p.x_bytes = (unsigned)x_extent;
+    // pairs of adjacent reduction elements: same image and same output row, 8-byte aligned in gy
+    const bool pairs_ok = ((g.OH * g.OW) & 1) == 0 && (g.OW & 1) == 0 && (gy_bs & 1) == 0 && (chunk & 1) == 0 &&
+                          (reinterpret_cast<uintptr_t>(gy) & 7) == 0 && x_extent > 0 && x_extent < (1ll << 31) - (1 << 20);
+    if (pairs_ok && !path_disabled("wbx6")) {
+        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+        else conv_wgrad_bx6_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    } else if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
     else if (bm == 96) conv_wgrad_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
     else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
     else conv_wgrad_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);

@@ -201,7 +201,10 @@ def test_spectral_norm_layers_golden(name, uvg):
     got = {k: p.grad.cpu() for k, p in mod.named_parameters() if p.grad is not None}
     assert set(got) == set(want), set(got) ^ set(want)
     for k in want:
-        assert_close(got[k], want[k], 1e-4, k)
+        # du, dv are dsigma * (W v, W^T u) with dsigma = -<G, W_bar> / sigma^2, a sum with heavy cancellation: rounding
+        # differences of 1e-7 in G (summation order; measured against float64 in tools/conv_accuracy.py) show up
+        # amplified ~1000x in these two, in the reference's own fp32 arithmetic as much as in ours
+        assert_close(got[k], want[k], 5e-4 if k.endswith(("weight_u", "weight_v")) else 1e-4, k)
 
 
 def test_batched_spectral_norm_equals_per_layer():
