@@ -31,8 +31,6 @@ int locate_device_info(char* arch_name, int name_len, int* cu_count, int* wave_s
 /* ---- RootTanh: y = (x^2+1)^(1/4) tanh x and its hand-written derivative (libs/activation.py:7-36) ---- */
 int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
-/* gx = gy * RootTanh'(x) + gadd (a layer output consumed both by RootTanh and directly, libs/linear.py:8-11) */
-int locate_roottanh_bwd_add(const float* x, const float* gy, const float* gadd, float* gx, int64_t n, void* stream);
 /* generator output tanh (libs/models.py:66); backward takes the forward OUTPUT y */
 int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream);
@@ -125,17 +123,14 @@ int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* pa
 int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
 /* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride] */
-/* fused epilogue (both nullable): act_out (batch stride act_bs) also receives RootTanh(y) - the activation between the
- * two convs of a stage (libs/conv.py:22-24); dact_src (batch stride dact_bs): y is multiplied by RootTanh'(dact_src),
- * i.e. the call is the data gradient of the layer FOLLOWING that activation (libs/activation.py:22-36) */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
-                    int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, float* act_out,
-                    int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace, void* stream);
+                    int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
+                    void* stream);
 /* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
-                      int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, float* act_out,
-                      int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace, void* stream);
+                      int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
+                      void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.

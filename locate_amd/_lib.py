@@ -26,7 +26,6 @@ PROTOTYPES = {
     "locate_device_info": (c_i, [ctypes.c_char_p, c_i, c_ip, c_ip]),
     "locate_roottanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
-    "locate_roottanh_bwd_add": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p]),
     "locate_tanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "locate_tanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "locate_norm_stats_workspace_bytes": (c_sz, []),
@@ -62,9 +61,9 @@ PROTOTYPES = {
     "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip]),
     "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
+    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
+    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
     "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),

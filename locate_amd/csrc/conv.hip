@@ -312,9 +312,6 @@ struct IgParams {
     const float* scale;  // multiplies the contraction (1/sigma of spectral norm) or null; one value, or one per GROUP of
     int scale_bg;        //   scale_bg consecutive batch elements (scale_bg = 0: a single value), scale_stride floats apart
     int scale_stride;
-    float* act_out;          // nullable: additionally receives RootTanh(out) (the activation that follows the conv)
-    const float* dact_src;   // nullable: out is multiplied by RootTanh'(dact_src) at the same position (the conv is the
-    long long act_bs, dact_bs;   //        data gradient of the layer that follows that activation); batch strides
     long long in_bs, out_bs;
     unsigned in_bytes;   // extent of the gathered tensor view in bytes (< 2^31): bound of the gather's buffer descriptor
     int B, C, H, W;      // gathered tensor: C = reduction channels
@@ -327,7 +324,7 @@ struct IgParams {
 };
 
 // Shared epilogue of the implicit-GEMM kernels (both MFMA flavours have the same 32x32 accumulator layout).
-template <int WGM, int WGN, int TM, int TN, bool EPI>
+template <int WGM, int WGN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN], int N, int n0,
                                                int m0, int zsplit, int wm, int wn, int lane) {
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -336,8 +333,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
     const bool split = p.ksplit > 1;
     const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
     float col_scale[TN];           // 1/sigma of the column's group (the batch may stack several forwards)
-    float* actp[TN];               // EPI: same position in act_out / dact_src
-    const float* dptr[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nj = n0 + (wn * TN + j) * 32 + lcol;
@@ -350,10 +345,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
         const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
                                : p.out + (long long)b * p.out_bs + pix;
         optr[j] = nj < N ? o : nullptr;
-        if (EPI) {
-            actp[j] = p.act_out ? p.act_out + (long long)b * p.act_bs + pix : nullptr;
-            dptr[j] = p.dact_src ? p.dact_src + (long long)b * p.dact_bs + pix : nullptr;
-        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -372,14 +363,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) {
-                    float val = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
-                    if (EPI && !split) {
-                        if (dptr[j]) val = roottanh_grad_f(dptr[j][(long long)m * plane], val);
-                        if (actp[j]) actp[j][(long long)m * plane] = roottanh_f(val);
-                    }
-                    o[(long long)m * plane] = val;
-                }
+                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
             }
         }
     }
@@ -444,7 +428,7 @@ __device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsig
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int WGM, int WGN, int TM, int TN, bool EPI>
+template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     constexpr int BK = IG_BK;
     constexpr int BM = WGM * TM * 32;
@@ -566,7 +550,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<WGM, WGN, TM, TN, EPI>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,7 +564,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // ---------------------------------------------------------------------------------------------
 #define B6_BK 16
 
-template <int WGM, int WGN, int TM, int TN, bool EPI>
+template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p) {
     constexpr int BK = B6_BK, KB = BK / 8;
     constexpr int BM = WGM * TM * 32;
@@ -700,16 +684,14 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         store_tiles(buf ^ 1);
         __syncthreads();
     }
-    igemm_epilogue<WGM, WGN, TM, TN, EPI>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
 }
 
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 int scale_bg, int scale_stride, int B, int M, int plane,
-                                                                long long out_bs, long long slab_stride, int ksplit,
-                                                                float* __restrict__ act_out, long long act_bs,
-                                                                const float* __restrict__ dact_src, long long dact_bs) {
+                                                                long long out_bs, long long slab_stride, int ksplit) {
     const long long per_b = (long long)M * plane;
     const long long total = (long long)B * per_b;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -719,9 +701,7 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
         for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
         if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
         if (bias) acc += bias[(int)(r / plane)];
-        if (dact_src) acc = roottanh_grad_f(dact_src[b * dact_bs + r], acc);
         out[b * out_bs + r] = acc;
-        if (act_out) act_out[b * act_bs + r] = roottanh_f(acc);
     }
 }
 
@@ -779,19 +759,9 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     for (int m = 0; m < MT; ++m) {
         if (m < p.M) {
             const float bv = p.bias ? p.bias[m] : 0.0f;
-            float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
-            if (p.dact_src) {
-                const float* dp = p.dact_src + (long long)b * p.dact_bs + q + (long long)m * HW;
-                v0 = roottanh_grad_f(dp[0], v0);
-                if (PX == 2) v1 = roottanh_grad_f(dp[1], v1);
-            }
+            const float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
             if (PX == 2) *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(v0, v1);
             else op[(long long)m * HW] = v0;
-            if (p.act_out) {
-                float* ap = p.act_out + (long long)b * p.act_bs + q + (long long)m * HW;
-                ap[0] = roottanh_f(v0);
-                if (PX == 2) ap[1] = roottanh_f(v1);
-            }
         }
     }
 }
@@ -870,35 +840,22 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     if (p.ksplit > min_kpad / IG_BK) p.ksplit = min_kpad / IG_BK;
     if (p.ksplit < 1) p.ksplit = 1;
     dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
-    const bool epi = (p.act_out || p.dact_src) && p.ksplit == 1;       // with split-K the slab reduction applies them
     if (!path_disabled("bx6")) {
-        if (epi) {
-            if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
-            else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, true><<<grid, 256, 0, st>>>(p);
-            else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, true><<<grid, 256, 0, st>>>(p);
-            else conv_igemm_bx6_kernel<1, 4, 1, 1, true><<<grid, 256, 0, st>>>(p);
-        } else {
-            if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(p);
-            else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, false><<<grid, 256, 0, st>>>(p);
-            else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, false><<<grid, 256, 0, st>>>(p);
-            else conv_igemm_bx6_kernel<1, 4, 1, 1, false><<<grid, 256, 0, st>>>(p);
-        }
-    } else if (epi) {
-        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
-        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, true><<<grid, 256, 0, st>>>(p);
-        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, true><<<grid, 256, 0, st>>>(p);
-        else conv_igemm_kernel<1, 4, 1, 1, true><<<grid, 256, 0, st>>>(p);
+        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_bx6_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     } else {
-        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(p);
-        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1, false><<<grid, 256, 0, st>>>(p);
-        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1, false><<<grid, 256, 0, st>>>(p);
-        else conv_igemm_kernel<1, 4, 1, 1, false><<<grid, 256, 0, st>>>(p);
+        if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     }
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
         igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
-                                                                         p.slab_stride, p.ksplit, p.act_out, p.act_bs, p.dact_src, p.dact_bs);
+                                                                         p.slab_stride, p.ksplit);
         LOCATE_LAUNCH_CHECK(who);
     }
     return LOCATE_OK;
@@ -1079,15 +1036,14 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
 }
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
-                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* act_out,
-                     int64_t act_bs, const float* dact_src, int64_t dact_bs, float* ws, hipStream_t st, const char* who) {
+                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st,
+                     const char* who) {
     IgParams p;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
     p.scale_bg = scale_bg; p.scale_stride = scale_stride;
-    p.act_out = act_out; p.act_bs = act_bs; p.dact_src = dact_src; p.dact_bs = dact_bs;
     {
         const long long extent = 4ll * ((long long)(p.B - 1) * in_bs + (long long)p.C * p.H * p.W);
         LOCATE_REQUIRE(in_bs >= 0 && extent > 0 && extent < (1ll << 31) - (1 << 20), "%s: gathered tensor of %lld bytes exceeds the 2 GiB a buffer descriptor addresses", who, extent);
@@ -1113,18 +1069,14 @@ LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) { return ig
 // x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
 // scale (nullable): scale_group_batch = 0 -> one device scalar; > 0 -> batch element b uses
 // scale[(b / scale_group_batch) * scale_stride] (several forwards stacked along the batch, each with its own sigma).
-// Fused epilogue (both nullable): act_out [B, M, OH, OW] (batch stride act_bs) also receives RootTanh(y);
-// dact_src (batch stride dact_bs): y is multiplied by RootTanh'(dact_src) - the backward of an activation that
-// precedes the layer whose data gradient this call computes (libs/conv.py:22-24, libs/activation.py:22-36).
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               float* act_out, int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace,
-                               void* stream) {
+                               void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
-    return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, act_out, act_bs, dact_src,
-                     dact_bs, static_cast<float*>(workspace), as_stream(stream), "locate_conv_fwd");
+    return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
+                     as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
@@ -1132,13 +1084,12 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 float* act_out, int64_t act_bs, const float* dact_src, int64_t dact_bs, void* workspace,
-                                 void* stream) {
+                                 void* workspace, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
-    return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs, act_out, act_bs, dact_src,
-                     dact_bs, static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
+    return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
+                     static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -74,23 +74,6 @@ LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, i
     return LOCATE_OK;
 }
 
-// gx = gy * RootTanh'(x) + gadd: the two gradient paths into a layer output that feeds both an activation and a second
-// consumer (the style Linears of the generator: libs/linear.py:8-11 returns (nlin(out), out)).
-__global__ void __launch_bounds__(256) roottanh_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                               const float* __restrict__ gadd, float* __restrict__ gx, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        gx[i] = roottanh_grad_f(x[i], gy[i]) + gadd[i];
-}
-
-LOCATE_API int locate_roottanh_bwd_add(const float* x, const float* gy, const float* gadd, float* gx, int64_t n, void* stream) {
-    LOCATE_REQUIRE(n >= 0 && x && gy && gadd && gx, "locate_roottanh_bwd_add: bad arguments");
-    if (n == 0) return LOCATE_OK;
-    roottanh_bwd_add_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(x, gy, gadd, gx, n);
-    LOCATE_LAUNCH_CHECK("locate_roottanh_bwd_add");
-    return LOCATE_OK;
-}
-
 LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_tanh_fwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;

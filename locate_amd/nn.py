@@ -134,14 +134,10 @@ class SpectralNorm(nn.Module):
             pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
         return pre
 
-    def forward(self, x, with_act=False):
-        """with_act: returns (y, RootTanh(y)), both from the same launch."""
+    def forward(self, x):
         m = self.module
         x4, w4, spec, restore = self._plan(x)
-        pre = self.take_pre()
-        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, pre, with_act)
-        if with_act:
-            return restore(y[0]), restore(y[1])
+        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, self.take_pre())
         return restore(y)
 
 
@@ -300,16 +296,6 @@ class ActivatedBaseConv(nn.Module):
 
     def forward(self, function_input, pre_activated=False):
         h = function_input if pre_activated else ops.root_tanh(function_input)
-        m0, m1 = self.conv_0.module, self.conv_1.module
-        if m0.bias is None and m1.bias is None and h.dim() == 4 and not ops.path_disabled("pair"):
-            # both convs and the RootTanh between them as one autograd node (activation fused into the conv epilogues)
-            _, w0, spec0, r0 = self.conv_0._plan(h)
-            _, w1, spec1, r1 = self.conv_1._plan(h[:, :0])        # 1x1 conv: the plan does not depend on the input
-            if r0 is _identity and r1 is _identity and w0 is m0.weight_bar and w1 is m1.weight_bar:
-                sig0, wv0 = self.conv_0.take_pre()
-                sig1, wv1 = self.conv_1.take_pre()
-                return ops.ActivatedPairFn.apply(h, w0, m0.weight_u, m0.weight_v, sig0, wv0, spec0,
-                                                 w1, m1.weight_u, m1.weight_v, sig1, wv1, spec1)
         return self.conv_1(ops.root_tanh(self.conv_0(h)))
 
 
@@ -338,11 +324,8 @@ class LinearModule(nn.Module):
         self.nlin = NonLinear()
 
     def forward(self, function_input):
-        if ops.path_disabled("linact"):
-            out = self.module(function_input)
-            return self.nlin(out), out
-        out, act = self.module(function_input, with_act=True)      # nlin(out) comes out of the same launch
-        return act, out
+        out = self.module(function_input)
+        return self.nlin(out), out
 
 
 class Block(nn.Module):

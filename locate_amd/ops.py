@@ -30,12 +30,6 @@ def _c(t, what="tensor"):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def path_disabled(name):
-    """Debugging knob for A/B timing: LOCATE_DISABLE=pair,pointwise,... switches optional fused paths off."""
-    import os
-    return name in os.environ.get("LOCATE_DISABLE", "").split(",")
-
-
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -532,58 +526,37 @@ def _sigma_args(sigma, batch):
     return groups, batch // groups, sigma.stride(0), sigma[0, 1:]
 
 
-def _fuse_act_max():
-    """Largest tensor (elements) whose RootTanh is fused into the producing conv's epilogue.  Small layers are
-    launch-bound (one launch less wins); on big ones the serial per-lane transcendental tail of the MFMA kernel costs
-    more than a separate full-bandwidth element-wise pass (measured: fusing everywhere was 0.3 ms/step slower)."""
-    import os
-    return int(os.environ.get("LOCATE_FUSE_ACT_MAX", 1 << 19))
-
-
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, want_act=False):
-    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`); with `want_act` also
-    RootTanh(y) - from the same launch for small tensors.  Returns (y, act or None)."""
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape):
+    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
     L = lib()
     st = _stream()
     y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-    act = torch.empty_like(y) if want_act else None
-    if want_act and y.numel() > _fuse_act_max():
-        y, _ = _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape)
-        check(L.locate_roottanh_fwd(_p(y), _p(act), y.numel(), st), "locate_roottanh_fwd")
-        return y, act
     _, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
-    abs_ = _bs(act) if want_act else 0
     if spec.kind == "conv":
         ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
         check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                _bs(y), _p(act), abs_, None, 0, _p(ws), st), "locate_conv_fwd")
+                                _bs(y), _p(ws), st), "locate_conv_fwd")
     else:
         ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
         check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                  _bs(y), _p(act), abs_, None, 0, _p(ws), st), "locate_conv_dgrad")
-    return y, act
+                                  _bs(y), _p(ws), st), "locate_conv_dgrad")
+    return y
 
 
-def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, dact_src=None):
-    """Gradient w.r.t. the layer input; with `dact_src` (the pre-activation tensor the input was RootTanh of) the result
-    is already multiplied by RootTanh'(dact_src), i.e. it is the gradient w.r.t. that pre-activation."""
+def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma):
+    """Gradient w.r.t. the layer input."""
     L = lib()
     st = _stream()
-    if dact_src is not None and dact_src.numel() > _fuse_act_max():
-        g = _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma)
-        check(L.locate_roottanh_bwd(_p(dact_src), _p(g), _p(g), g.numel(), st), "locate_roottanh_bwd")     # in place
-        return g
     gx = torch.empty_like(x_like)
     _, sbg, sst, inv_sigma = _sigma_args(sigma, gy.shape[0])
-    dbs = _bs(dact_src) if dact_src is not None else 0
     if spec.kind == "conv":
         ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), gy.device)
         check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, None, _p(gx),
-                                  _bs(gx), None, 0, _p(dact_src), dbs, _p(ws), st), "locate_conv_dgrad")
+                                  _bs(gx), _p(ws), st), "locate_conv_dgrad")
     else:
         ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), gy.device)
         check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, None, _p(gx),
-                                _bs(gx), None, 0, _p(dact_src), dbs, _p(ws), st), "locate_conv_fwd")
+                                _bs(gx), _p(ws), st), "locate_conv_fwd")
     return gx
 
 
@@ -642,52 +615,37 @@ class SNConvFn(torch.autograd.Function):
     (S x 1)/(1 x S) feature-attention convs are reshaped to 1x1 convs by the caller).  sigma / wv are the
     results of THIS forward's power iteration; u, v are inputs only so that their gradients can be returned
     (the reference's main.py:172 makes them trainable) - they are read at backward time, i.e. with the values
-    left by the latest forward, exactly like the reference's autograd does.
-    with_act: returns (y, RootTanh(y)) from the same launch (libs/linear.py:8-11)."""
+    left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, with_act=False):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec):
         x = _dense(x, "conv input")
         w = _c(w_bar, "weight_bar")
         owner = _panel_owner(w_bar)
         geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
         garr = _geom(geom)
         b = _c(bias) if bias is not None else None
-        y, act = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, want_act=with_act)
+        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
-        ctx.groups, ctx.with_act = groups, with_act
-        if groups > 1 or with_act:
+        ctx.groups = groups
+        if groups > 1:
             ctx.save_for_backward(x, w, sigma, wv, y, b)     # stacked: <G_k, W_bar> is taken on the activation side
         else:
             ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.owner = owner
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
-        if with_act:
-            return y, act
         return y
 
     @staticmethod
-    def backward(ctx, gy, gact=None):
-        if ctx.groups > 1 or ctx.with_act:
+    def backward(ctx, gy):
+        if ctx.groups > 1:
             x, w, sigma, wv, y, bsaved = ctx.saved_tensors
         else:
             x, w, sigma, wv = ctx.saved_tensors
             y = bsaved = None
         spec, garr = ctx.spec, _geom(ctx.geom)
-        if ctx.with_act:
-            # two consumers of y: the direct one (gy) and RootTanh (gact)
-            if gact is None:
-                gy = _dense(gy, "conv output gradient")
-            elif gy is None:
-                gy = RootTanhFn_backward(y, gact)
-            else:
-                g = torch.empty_like(y)
-                check(lib().locate_roottanh_bwd_add(_p(y), _p(_c(gact)), _p(_c(gy)), _p(g), y.numel(), _stream()),
-                      "locate_roottanh_bwd_add")
-                gy = g
-        else:
-            gy = _dense(gy, "conv output gradient")
+        gy = _dense(gy, "conv output gradient")
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
         gx = gw = gu = gb = None
         if need_x:
@@ -699,65 +657,13 @@ class SNConvFn(torch.autograd.Function):
         if ctx.has_bias and need_b:
             gb = _bias_grad(gy)
         # gv is assigned to v.grad by _finalize_pending_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None, None
+        return gx, gw, gu, None, gb, None, None, None
 
 
-def RootTanhFn_backward(x, g):
-    gx = torch.empty_like(x)
-    check(lib().locate_roottanh_bwd(_p(x), _p(_c(g)), _p(gx), x.numel(), _stream()), "locate_roottanh_bwd")
-    return gx
-
-
-class ActivatedPairFn(torch.autograd.Function):
-    """y = conv_1(RootTanh(conv_0(h))) - the two spectral-normalised convs of one stage (libs/conv.py:14-24) with the
-    activation between them fused into conv_0's epilogue (forward) and into conv_1's data-gradient epilogue
-    (backward): no separate RootTanh launches, no extra pass over the stage's widest tensor."""
-
-    @staticmethod
-    def forward(ctx, h, w0_bar, u0, v0, sig0, wv0, spec0, w1_bar, u1, v1, sig1, wv1, spec1):
-        h = _dense(h, "conv input")
-        w0, w1 = _c(w0_bar, "weight_bar"), _c(w1_bar, "weight_bar")
-        own0, own1 = _panel_owner(w0_bar), _panel_owner(w1_bar)
-        geom0, shape0 = spec0.geometry(tuple(h.shape), tuple(w0.shape))
-        c0, a = _conv_apply(h, w0, own0, spec0, geom0, _geom(geom0), sig0, None, shape0, want_act=True)
-        geom1, shape1 = spec1.geometry(tuple(a.shape), tuple(w1.shape))
-        y, _ = _conv_apply(a, w1, own1, spec1, geom1, _geom(geom1), sig1, None, shape1)
-        ctx.groups = sig0.shape[0] if sig0.dim() == 2 else 1
-        ctx.save_for_backward(h, w0, sig0, wv0, c0, a, w1, sig1, wv1, y if ctx.groups > 1 else None)
-        ctx.params = (u0, v0, u1, v1)
-        ctx.meta = (own0, geom0, spec0, own1, geom1, spec1)
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        h, w0, sig0, wv0, c0, a, w1, sig1, wv1, y = ctx.saved_tensors
-        u0, v0, u1, v1 = ctx.params
-        own0, geom0, spec0, own1, geom1, spec1 = ctx.meta
-        garr0, garr1 = _geom(geom0), _geom(geom1)
-        gy = _dense(gy, "conv output gradient")
-        nd = ctx.needs_input_grad
-        need_h, need_w0, need_u0, need_v0 = nd[0], nd[1], nd[2], nd[3]
-        need_w1, need_u1, need_v1 = nd[7], nd[8], nd[9]
-        gh = gw0 = gu0 = gw1 = gu1 = None
-        if need_w1 or need_u1 or need_v1:
-            gw1, gu1 = _conv_weight_grad(a, gy, y, None, w1, u1, v1, sig1, wv1, spec1, garr1, need_u1, need_v1)
-            if not need_w1:
-                gw1 = None
-        if need_h or need_w0 or need_u0 or need_v0:
-            g_c0 = _conv_input_grad(gy, a, w1, own1, spec1, geom1, garr1, sig1, dact_src=c0)   # incl. RootTanh'(c0)
-            if need_w0 or need_u0 or need_v0:
-                gw0, gu0 = _conv_weight_grad(h, g_c0, c0, None, w0, u0, v0, sig0, wv0, spec0, garr0, need_u0, need_v0)
-                if not need_w0:
-                    gw0 = None
-            if need_h:
-                gh = _conv_input_grad(g_c0, h, w0, own0, spec0, geom0, garr0, sig0)
-        return gh, gw0, gu0, None, None, None, None, gw1, gu1, None, None, None, None
-
-
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, with_act=False):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
-    batched update is supplied.  with_act: returns (y, RootTanh(y))."""
+    batched update is supplied."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, with_act)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec)
