@@ -79,11 +79,11 @@ def main():
 
         def r_fwd(inp, out):      # R forward
             check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                    out.stride(0), None, 0, None, 0, ws_f.data_ptr(), st))
+                                    out.stride(0), ws_f.data_ptr(), st))
 
         def r_dgrad(inp, out):    # R data adjoint
             check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                      out.stride(0), None, 0, None, 0, ws_d.data_ptr(), st))
+                                      out.stride(0), ws_d.data_ptr(), st))
 
         if kind == "conv":
             fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
