@@ -411,13 +411,31 @@ def gen_init():
 
 def gen_config1():
     """G11: config 1 (32x32 RGB bs 8, full width): losses and per-tensor norms of one step."""
+    _gen_step_record("g11_config1", 32, 8, 8)
+
+
+def gen_config3():
+    """G12: the reference's default architecture (128x128, full width; BASELINE.json configs[3]) at batch 2."""
+    _gen_step_record("g12_config3_128", 128, 2, 8)
+
+
+def gen_config2():
+    """G14: BASELINE.json configs[1], the benchmark workload itself (64x64, batch 64, full width)."""
+    _gen_step_record("g14_config2_64", 64, 64, 8)
+
+
+def gen_size256():
+    """G13: the 256x256 architecture (BASELINE.json configs[4]: attention up to N = 65 536) at 1/8 width, batch 2."""
+    _gen_step_record("g13_256_narrow", 256, 2, 1)
+
+
+def _gen_step_record(name, S, B, ff):
     import warnings
     import torch
     from ref_loader import load_reference
-    ns = load_reference(32, 8)
+    ns = load_reference(S, ff)
     warnings.simplefilter("ignore")
     G, GO, D, DO = _build_models(ns, 999)
-    B, S = 8, 32
     latent = torch.randn(B, S)
     real = torch.randn(B, 3, S, S).clamp(-1, 1)
     aug = torch.randn(B, 3, S, S).clamp(-1, 1)
@@ -433,10 +451,11 @@ def gen_config1():
     for tag, sd in (("D", rec["d_sd_post_step"]), ("G", rec["g_sd_post_step"])):
         d[tag + "/post_keys"] = np.array(list(sd.keys()))
         d[tag + "/post_norms"] = np.array([float(v.double().norm()) for v in sd.values()])
-    _save("g11_config1", d)
+    _save(name, d)
 
 
-GROUPS = {"ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1}
+GROUPS = {"ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
+          "config2": gen_config2, "size256": gen_size256}
 
 
 def main(argv):
@@ -444,7 +463,7 @@ def main(argv):
         GROUPS[argv[1]]()
         return
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    runs = [("ops", {}), ("tiny", {}), ("config1", {})]
+    runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {})]
     runs += [("init", {"LOCATE_GOLDEN_INIT_CFG": c}) for c in ("tiny32", "full32", "full64")]
     for name, extra in runs:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), name], env=dict(env, **extra),

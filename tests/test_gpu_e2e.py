@@ -106,22 +106,30 @@ def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d):
     assert_close(img.cpu(), z["sample/image"], 1e-3)
 
 
-def test_config1_full_width_step_vs_reference_record():
-    """Config 1 (32x32 RGB, bs 8, full width): seeded construction + one step; losses, output and per-tensor
-    gradient / post-step norms against what the reference produced (g11_config1.npz)."""
+@pytest.mark.parametrize("name,S,B,ff,stacked", [
+    ("g11_config1", 32, 8, 8, False),         # BASELINE configs[0]: 32x32, batch 8, full width
+    ("g11_config1", 32, 8, 8, True),
+    ("g14_config2_64", 64, 64, 8, True),      # configs[1]: the benchmark workload itself, from the reference
+    ("g12_config3_128", 128, 2, 8, True),     # configs[3]: the reference's default 128x128 architecture (C up to 1536)
+    ("g13_256_narrow", 256, 2, 1, True),      # configs[4]'s 256x256 architecture at 1/8 width (attention over N = 65 536)
+])
+def test_full_architectures_step_vs_reference_record(name, S, B, ff, stacked):
+    """Seeded construction + one step of the full architectures; losses, output and per-tensor gradient / post-step
+    norms against what the reference produced (oracle/gen_golden.py: g11 - g14)."""
     from locate_amd import Discriminator, Generator, NetConfig, TrainStep, get_model
-    z = load_golden("g11_config1")
-    cfg = NetConfig(image_size=32)
+    z = load_golden(name)
+    cfg = NetConfig(image_size=S, base_feature_factor=ff)
     torch.manual_seed(cfg.seed)
     dev = torch.device("cuda:0")
     G, GO = get_model(Generator(cfg), cfg.glr, dev)
     D, DO = get_model(Discriminator(cfg), cfg.dlr, dev)
-    B, S = 8, 32
+    G.batched_spectral_norm = D.batched_spectral_norm = stacked
     latent = torch.randn(B, S)
     real = torch.randn(B, 3, S, S).clamp(-1, 1)
     aug = torch.randn(B, 3, S, S).clamp(-1, 1)
     np.testing.assert_array_equal(latent[0, :4].numpy(), z["after_build_rng_check"])
     step = TrainStep(G, D, GO, DO)
+    assert step.stacked_d == stacked
     rec = {}
     d_orig, g_orig = DO.step, GO.step
 

@@ -243,3 +243,38 @@ def test_config_feature_lists():
     c = O.NetConfig(256)
     assert c.g_features() == [256, 3072, 1536, 768, 384, 192, 96, 48]
     assert c.d_features() == [32, 64, 128, 256, 512, 1024, 2048, 2048]
+
+
+@pytest.mark.parametrize("name,S,B,ff", [("g11_config1", 32, 8, 8), ("g13_256_narrow", 256, 2, 1)])
+def test_oracle_full_architectures_vs_reference_record(name, S, B, ff):
+    """The CPU oracle on the full architectures (seeded construction through the host mirror, which reproduces the
+    reference's RNG draw order): losses, output and per-tensor gradient norms of one step as recorded from the
+    reference (oracle/gen_golden.py g11 / g13)."""
+    from locate_amd import Discriminator, Generator, NetConfig, init
+    z = load_golden(name)
+    cfg = NetConfig(image_size=S, base_feature_factor=ff)
+    torch.manual_seed(cfg.seed)
+    G = Generator(cfg)
+    G.apply(init)
+    D = Discriminator(cfg)
+    D.apply(init)
+    latent = torch.randn(B, S)
+    real = torch.randn(B, 3, S, S).clamp(-1, 1)
+    aug = torch.randn(B, 3, S, S).clamp(-1, 1)
+    np.testing.assert_array_equal(latent[0, :4].numpy(), z["after_build_rng_check"])
+    ocfg = O.NetConfig(image_size=S, base_feature_factor=ff)
+    PG = O.make_params({k: v.clone() for k, v in G.state_dict().items()})
+    PD = O.make_params({k: v.clone() for k, v in D.state_dict().items()})
+    og, od = O.Nadam(ocfg.glr, (ocfg.beta1, ocfg.beta2)), O.Nadam(ocfg.dlr, (ocfg.beta1, ocfg.beta2))
+    rec = O.train_step(PG, PD, G.noise.clone(), og, od, latent, real, aug, ocfg)
+    for k in ("d_true", "d_gen", "d_error", "penalty", "g_error"):
+        assert_close(rec[k].reshape(z[k].shape), z[k], 2e-5, k)
+    assert_close(rec["fake"].flatten()[:16], z["fake_first"], 2e-5)
+    for tag, got in (("D", rec["d_grads"]), ("G", rec["g_grads"])):
+        keys = z[tag + "/grad_keys"].tolist()
+        assert sorted(keys) == sorted(got)
+        want = dict(zip(keys, z[tag + "/grad_norms"]))
+        scale = max(want.values())
+        for k in keys:
+            g = float(got[k].double().norm())
+            assert abs(g - want[k]) <= 2e-4 * max(want[k], 1e-3 * scale), (tag, k, g, want[k])
