@@ -121,10 +121,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hook: LOCATE_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that) to exercise the
+    # data-parallel control flow on a single-GPU box; the driver's runs use one GPU per rank over RCCL
+    backend = os.environ.get("LOCATE_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from locate_amd import Discriminator, Generator, NetConfig, TrainStep, get_model
     from locate_amd._lib import require_gpu
@@ -175,6 +182,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1:
+        # replicas must still be identical after the timed steps (same averaged gradients, same deterministic kernels)
+        chk = torch.stack([sum(p.detach().double().sum() for p in net.parameters()) for net in (G, D)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged: parameter checksums %s vs %s" % (lo.tolist(), hi.tolist())
     d_error = float(out["d_error"])
     g_error = float(out["g_error"])
     assert d_error == d_error and g_error == g_error, "non-finite loss in the benchmark"

@@ -1,5 +1,5 @@
-"""Whole-step hipGraph capture.  One G+D iteration is ~3000 small launches (the reference's Python issues about
-as many ATen calls); replaying them as graphs removes the host from the loop - the MI355X-native replacement
+"""Whole-step hipGraph capture.  One G+D iteration is ~1100 launches (the reference's Python issues several thousand
+ATen calls); replaying them as graphs removes the host from the loop - the MI355X-native replacement
 for a tracing compiler.  Everything the step mutates (weights, spectral-norm u/v, Nadam moments and schedule
 counters) lives in device memory at fixed addresses, so one replay == one more training iteration.
 

@@ -135,12 +135,18 @@ class GradAllReducer:
         self._handles.append((b, members, work))
 
     @staticmethod
-    def _pack(flat, grads):
-        off = 0
+    def _views(flat, grads):
+        views, off = [], 0
         for g in grads:
             n = g.numel()
-            flat[off:off + n].copy_(g.reshape(-1))
+            views.append(flat[off:off + n].view_as(g))
             off += n
+        return views
+
+    @classmethod
+    def _pack(cls, flat, grads):
+        # one multi-tensor launch per bucket instead of one copy per gradient (~140 tensors per network)
+        torch._foreach_copy_(cls._views(flat, grads), [g if g.is_contiguous() else g.contiguous() for g in grads])
 
     def finish(self):
         """Call after backward(), before optimizer.step(): afterwards every .grad holds the rank mean."""
@@ -187,9 +193,10 @@ class GradAllReducer:
             self._unpack(flat, members, inv)
 
     def _unpack(self, flat, members, inv):
-        off = 0
-        for i in members:
-            g = self.params[i].grad
-            n = g.numel()
-            g.copy_((flat[off:off + n] * inv).view_as(g))
-            off += n
+        grads = [self.params[i].grad for i in members]
+        flat.mul_(inv)
+        if all(g.is_contiguous() for g in grads):
+            torch._foreach_copy_(grads, self._views(flat, grads))
+        else:
+            for g, v in zip(grads, self._views(flat, grads)):
+                g.copy_(v)
