@@ -1255,9 +1255,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
         const int b = fastdiv(nn, p.q_mul, p.q_s1, p.q_s2), q = nn - b * Q;
         const int oh = fastdiv(q, p.ow_mul, p.ow_s1, p.ow_s2), ow = q - oh * p.OW;
         const float* gp = p.gy + (long long)b * p.gy_bs + q;
-        if (p.gscale_bg > 0) {
-            const int grp = b / p.gscale_bg;
-            gsc = grp == 0 ? gs0 : grp == 1 ? gs1 : grp == 2 ? gs2 : gs3;
+        if (p.gscale_bg > 0) {       // group of batch element b (at most 4 groups): compares, no division in the hot loop
+            const int bg = p.gscale_bg;
+            gsc = gs0;
+            gsc = b >= bg ? gs1 : gsc;
+            gsc = b >= 2 * bg ? gs2 : gsc;
+            gsc = b >= 3 * bg ? gs3 : gsc;
         }
         gmask = 0;
 #pragma unroll
@@ -1404,9 +1407,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bx6_kernel(const WgParams p
         const int b = fastdiv(nn, p.q_mul, p.q_s1, p.q_s2), q = nn - b * Q;
         const int oh = fastdiv(q, p.ow_mul, p.ow_s1, p.ow_s2), ow = q - oh * p.OW;
         const float* gp = p.gy + (long long)b * p.gy_bs + q;
-        if (p.gscale_bg > 0) {
-            const int grp = b / p.gscale_bg;
-            gsc = grp == 0 ? gs0 : grp == 1 ? gs1 : grp == 2 ? gs2 : gs3;
+        if (p.gscale_bg > 0) {       // group of batch element b (at most 4 groups): compares, no division in the hot loop
+            const int bg = p.gscale_bg;
+            gsc = gs0;
+            gsc = b >= bg ? gs1 : gsc;
+            gsc = b >= 2 * bg ? gs2 : gsc;
+            gsc = b >= 3 * bg ? gs3 : gsc;
         }
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
