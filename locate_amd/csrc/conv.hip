@@ -1551,7 +1551,7 @@ static int wgrad_reduce_zp(int nsplit, int64_t n) { return (nsplit >= 16 && n < 
 static int wgrad_reduce_grid(int64_t n, int nsplit) {
     const int epb = 256 / wgrad_reduce_zp(nsplit, n);
     int g = stream_grid(n, epb);
-    return g > 512 ? 512 : g;
+    return g > 2048 ? 2048 : g;
 }
 
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {

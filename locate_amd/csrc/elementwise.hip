@@ -119,40 +119,75 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__
     }
 }
 
-// One wave per plane: dx, da (full, or gamma * sum x*g per plane in broadcast mode) and, per BLOCK, the sum of
-// x^2*g over the planes the block visited (fixed order: deterministic).
+// dx, da (full, or gamma * sum x*g per plane in broadcast mode) and, per BLOCK, the sum of x^2*g over the planes the
+// block visited (fixed order: deterministic).  WPP waves share a plane: 1 for small planes (one wave per plane),
+// 4 (the whole block) for planes of >= 1024 elements, 16-byte accesses when hw % 4 == 0.
+template <int WPP>
 __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                              const float* __restrict__ gamma, const float* __restrict__ g,
                                                              float* __restrict__ dx, float* __restrict__ da_full,
                                                              float* __restrict__ da_plane, double* __restrict__ block_x2g,
                                                              int64_t planes, int hw, int a_per_plane) {
-    __shared__ double wsum[4];
+    __shared__ double wsum[4], px2g[4];
+    __shared__ float pxg[4];
     double wacc = 0.0;
     const float gm = gamma[0];
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t p = wave; p < planes; p += nwaves) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = WPP == 1 ? lane : (int)threadIdx.x;              // position inside the plane's worker group
+    const int nsub = WPP == 1 ? 64 : 256;
+    const int64_t first = WPP == 1 ? (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) : (int64_t)blockIdx.x;
+    const int64_t step = WPP == 1 ? (((int64_t)gridDim.x * blockDim.x) >> 6) : (int64_t)gridDim.x;
+    const bool vec = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
+                                        (a_per_plane ? 0 : (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(da_full)))) & 15) == 0;
+    for (int64_t p = first; p < planes; p += step) {
         const int64_t base = p * hw;
         const float ap = a_per_plane ? a[p] : 0.0f;
         float sxg = 0.0f, sx2g = 0.0f;
-        for (int i = lane; i < hw; i += 64) {
-            const float xv = x[base + i], gv = g[base + i];
-            const float av = a_per_plane ? ap : a[base + i];
-            const float xg = xv * gv;
-            dx[base + i] = fmaf(gm, av, 1.0f) * gv;
-            if (!a_per_plane) da_full[base + i] = xg * gm;
-            sxg += xg;
-            sx2g = fmaf(xg, xv, sx2g);
+        if (vec) {
+            for (int i = sub; i < (hw >> 2); i += nsub) {
+                const float4 xv = reinterpret_cast<const float4*>(x + base)[i], gv = reinterpret_cast<const float4*>(g + base)[i];
+                float4 av = make_float4(ap, ap, ap, ap);
+                if (!a_per_plane) av = reinterpret_cast<const float4*>(a + base)[i];
+                const float4 xg = make_float4(xv.x * gv.x, xv.y * gv.y, xv.z * gv.z, xv.w * gv.w);
+                reinterpret_cast<float4*>(dx + base)[i] = make_float4(fmaf(gm, av.x, 1.0f) * gv.x, fmaf(gm, av.y, 1.0f) * gv.y,
+                                                                      fmaf(gm, av.z, 1.0f) * gv.z, fmaf(gm, av.w, 1.0f) * gv.w);
+                if (!a_per_plane) reinterpret_cast<float4*>(da_full + base)[i] = make_float4(xg.x * gm, xg.y * gm, xg.z * gm, xg.w * gm);
+                sxg += (xg.x + xg.y) + (xg.z + xg.w);
+                sx2g += (xg.x * xv.x + xg.y * xv.y) + (xg.z * xv.z + xg.w * xv.w);
+            }
+        } else {
+            for (int i = sub; i < hw; i += nsub) {
+                const float xv = x[base + i], gv = g[base + i];
+                const float av = a_per_plane ? ap : a[base + i];
+                const float xg = xv * gv;
+                dx[base + i] = fmaf(gm, av, 1.0f) * gv;
+                if (!a_per_plane) da_full[base + i] = xg * gm;
+                sxg += xg;
+                sx2g = fmaf(xg, xv, sx2g);
+            }
         }
         sxg = wave_sum(sxg);
-        sx2g = wave_sum(sx2g);
-        wacc += (double)sx2g;
-        if (lane == 0 && a_per_plane) da_plane[p] = gm * sxg;
+        const double s2 = wave_sum_d((double)sx2g);      // dgamma sums x^2 g with heavy cancellation: leave fp32 early
+        if (WPP == 1) {
+            wacc += s2;
+            if (lane == 0 && a_per_plane) da_plane[p] = gm * sxg;
+        } else {
+            __syncthreads();
+            if (lane == 0) { pxg[wid] = sxg; px2g[wid] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                wacc += (px2g[0] + px2g[1]) + (px2g[2] + px2g[3]);
+                if (a_per_plane) da_plane[p] = gm * ((pxg[0] + pxg[1]) + (pxg[2] + pxg[3]));
+            }
+        }
     }
-    if (lane == 0) wsum[threadIdx.x >> 6] = wacc;
-    __syncthreads();
-    if (threadIdx.x == 0) block_x2g[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (WPP == 1) {
+        if (lane == 0) wsum[wid] = wacc;
+        __syncthreads();
+        if (threadIdx.x == 0) block_x2g[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    } else if (threadIdx.x == 0) {
+        block_x2g[blockIdx.x] = wacc;
+    }
 }
 
 // dgamma = sum over blocks of block_x2g (reference bug: x^2 g, merge.py:33-38)
@@ -183,11 +218,17 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
                                void* stream) {
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
     double* block_x2g = static_cast<double*>(workspace);
-    int64_t blocks = cdiv64(planes, 4);
+    const bool whole_block = hw >= 1024;
+    int64_t blocks = whole_block ? planes : cdiv64(planes, 4);
     if (blocks > 4096) blocks = 4096;
-    gate_bwd_plane_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
-                                                                     a_per_plane ? da : nullptr, block_x2g, planes, hw,
-                                                                     a_per_plane);
+    if (whole_block)
+        gate_bwd_plane_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
+                                                                            a_per_plane ? da : nullptr, block_x2g, planes, hw,
+                                                                            a_per_plane);
+    else
+        gate_bwd_plane_kernel<1><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
+                                                                            a_per_plane ? da : nullptr, block_x2g, planes, hw,
+                                                                            a_per_plane);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
     gate_bwd_final_kernel<<<1, 256, 0, as_stream(stream)>>>(block_x2g, dgamma, (int)blocks);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(final)");

@@ -240,16 +240,28 @@ __global__ void __launch_bounds__(256) sn_rank1_kernel(const double* __restrict_
 __global__ void __launch_bounds__(256) sn_group_dot_kernel(const float* __restrict__ gy, int64_t gy_bs, const float* __restrict__ y,
                                                            int64_t y_bs, const float* __restrict__ bias, int Bg, int M, int plane,
                                                            double* __restrict__ partial) {
+    // blocks walk whole (batch, channel) planes: one division per plane, 16-byte loads inside
     __shared__ double scratch[16];
     const int grp = blockIdx.y;
-    const int64_t per_b = (int64_t)M * plane, total = (int64_t)Bg * per_b;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int planes = Bg * M;
+    const bool vec = (plane & 3) == 0 && (gy_bs & 3) == 0 && (y_bs & 3) == 0 && ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t bl = i / per_b, r = i - bl * per_b;
+    for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+        const int bl = pl / M, m = pl - bl * M;
         const int64_t b = (int64_t)grp * Bg + bl;
-        const float yv = y[b * y_bs + r] - (bias ? bias[(int)(r / plane)] : 0.0f);
-        acc += (double)gy[b * gy_bs + r] * (double)yv;
+        const float* gp = gy + b * gy_bs + (int64_t)m * plane;
+        const float* yp = y + b * y_bs + (int64_t)m * plane;
+        const float bv = bias ? bias[m] : 0.0f;
+        float part = 0.0f;
+        if (vec) {
+            for (int i = threadIdx.x; i < (plane >> 2); i += blockDim.x) {
+                const float4 g4 = reinterpret_cast<const float4*>(gp)[i], y4 = reinterpret_cast<const float4*>(yp)[i];
+                part += (g4.x * (y4.x - bv) + g4.y * (y4.y - bv)) + (g4.z * (y4.z - bv) + g4.w * (y4.w - bv));
+            }
+        } else {
+            for (int i = threadIdx.x; i < plane; i += blockDim.x) part = fmaf(gp[i], yp[i] - bv, part);
+        }
+        acc += (double)part;
     }
     acc = block_sum<double>(acc, scratch);
     if (threadIdx.x == 0) partial[(int64_t)grp * gridDim.x + blockIdx.x] = acc;
@@ -305,9 +317,7 @@ LOCATE_API int locate_sn_weight_bwd_grouped(const float* gy, int64_t gy_bs, cons
     LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd_grouped: du requested without the saved W v");
     hipStream_t st = as_stream(stream);
     double* partial = static_cast<double*>(workspace);
-    const int64_t total = (int64_t)Bg * M * plane;
-    int nb = stream_grid(total, 1024);
-    if (nb > 256) nb = 256;
+    int nb = Bg * M < 256 ? Bg * M : 256;      // the workspace holds 4 x 256 partial sums
     sn_group_dot_kernel<<<dim3(nb, groups), 256, 0, st>>>(gy, gy_bs, y, y_bs, bias, Bg, M, plane, partial);
     LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd_grouped(dot)");
     const int64_t n = (int64_t)h * wd;
