@@ -54,7 +54,8 @@ int locate_norm_bwd(const float* x, const float* g, const float* stats, const fl
                     const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw, int groups,
                     void* workspace, void* stream);
 /* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
-int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream);
+size_t locate_channel_sum_workspace_bytes(int B, int C, int hw);
+int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* workspace, void* stream);
 
 /* ---- residual gate out = (gamma a + 1) x (libs/merge.py:19-62), incl. dgamma = sum x^2 g as coded.
  *      a_per_plane = 1: `a` holds one value per (batch, channel) plane (stride-0 expand, libs/util_modules.py:6-12) */

@@ -1547,7 +1547,10 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     if (tiles_out) *tiles_out = (int)tiles;
 }
 
-static int wgrad_reduce_zp(int nsplit, int64_t n) { return (nsplit >= 16 && n < (1 << 20)) ? 4 : 1; }
+static int wgrad_reduce_zp(int nsplit, int64_t n) {
+    if (nsplit >= 64 && n < (1 << 16)) return 16;      // few outputs, many slabs: 16 threads share one output element
+    return (nsplit >= 16 && n < (1 << 20)) ? 4 : 1;
+}
 static int wgrad_reduce_grid(int64_t n, int nsplit) {
     const int epb = 256 / wgrad_reduce_zp(nsplit, n);
     int g = stream_grid(n, epb);
@@ -1620,7 +1623,9 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     if (!direct) {
         const int64_t n = (int64_t)g.M * p.R;
         const int rg = wgrad_reduce_grid(n, nsplit);
-        if (wgrad_reduce_zp(nsplit, n) == 4)
+        if (wgrad_reduce_zp(nsplit, n) == 16)
+            slab_reduce_kernel<16><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
+        else if (wgrad_reduce_zp(nsplit, n) == 4)
             slab_reduce_kernel<4><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
         else
             slab_reduce_kernel<1><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);

@@ -383,36 +383,77 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
 // per-channel sum over batch and space: out[c] = sum_{b,hw} g[b, c, hw]   (bias gradients of the 1x1 skip
 // convs, scale.py:28-34, and of the style Linears, linear.py:10)
 // ---------------------------------------------------------------------------------------------
-// One 1024-thread block per channel, 16-byte loads, fixed summation order (deterministic).
+// Blocks of 1024 threads: blockIdx.x = channel, blockIdx.y = batch slice (so that few channels still fill the chip),
+// 16-byte loads, fixed summation order (deterministic); a second tiny kernel adds the slices.
+#define CS_MAX_SLICES 64
 __global__ void __launch_bounds__(1024) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int C,
-                                                           int hw, int64_t batch_stride) {
+                                                           int hw, int64_t batch_stride, int per_slice) {
     __shared__ float scratch[16];
     const int c = blockIdx.x;
+    const int b0 = blockIdx.y * per_slice;
+    const int nb = min(per_slice, B - b0);
     float acc = 0.0f;
     const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
-    if (vec) {
-        const int hw4 = hw >> 2;
-        const int total = B * hw4;
-        for (int i = threadIdx.x; i < total; i += blockDim.x) {
-            const int b = i / hw4, r = i - b * hw4;
-            const float4 v = reinterpret_cast<const float4*>(g + (int64_t)b * batch_stride + (int64_t)c * hw)[r];
-            acc += (v.x + v.y) + (v.z + v.w);
-        }
-    } else {
-        const int total = B * hw;
-        for (int i = threadIdx.x; i < total; i += blockDim.x) {
-            const int b = i / hw, r = i - b * hw;
-            acc += g[(int64_t)b * batch_stride + (int64_t)c * hw + r];
+    if (nb > 0) {
+        if (vec) {
+            const int hw4 = hw >> 2;
+            const int total = nb * hw4;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int b = i / hw4, r = i - b * hw4;
+                const float4 v = reinterpret_cast<const float4*>(g + (int64_t)(b0 + b) * batch_stride + (int64_t)c * hw)[r];
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            const int total = nb * hw;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int b = i / hw, r = i - b * hw;
+                acc += g[(int64_t)(b0 + b) * batch_stride + (int64_t)c * hw + r];
+            }
         }
     }
     acc = block_sum<float>(acc, scratch);
-    if (threadIdx.x == 0) out[c] = acc;
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.y * C + c] = acc;
 }
 
-LOCATE_API int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* stream) {
+__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C,
+                                                                int slices) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.0f;
+    for (int s = 0; s < slices; ++s) acc += part[(int64_t)s * C + c];
+    out[c] = acc;
+}
+
+static int channel_sum_slices(int B, int C, int hw) {
+    if (C >= 512 || (int64_t)B * hw < 8192) return 1;          // enough blocks already, or too little work to split
+    int s = (1024 + C - 1) / C;
+    if (s > B) s = B;
+    if (s > CS_MAX_SLICES) s = CS_MAX_SLICES;
+    return s < 1 ? 1 : s;
+}
+
+LOCATE_API size_t locate_channel_sum_workspace_bytes(int B, int C, int hw) {
+    const int s = channel_sum_slices(B, C, hw);
+    return s > 1 ? (size_t)s * C * sizeof(float) : 0;
+}
+
+// workspace: locate_channel_sum_workspace_bytes(B, C, hw) (may be null when that is 0)
+LOCATE_API int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* workspace,
+                                  void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && batch_stride >= (int64_t)C * hw && (int64_t)B * hw < (1ll << 31),
                    "locate_channel_sum: bad shape");
-    channel_sum_kernel<<<C, 1024, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride);
+    const int slices = channel_sum_slices(B, C, hw);
+    if (slices == 1) {
+        channel_sum_kernel<<<dim3(C, 1), 1024, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride, B);
+        LOCATE_LAUNCH_CHECK("locate_channel_sum");
+        return LOCATE_OK;
+    }
+    LOCATE_REQUIRE(workspace, "locate_channel_sum: missing workspace");
+    float* part = static_cast<float*>(workspace);
+    const int per_slice = (B + slices - 1) / slices;
+    channel_sum_kernel<<<dim3(C, slices), 1024, 0, as_stream(stream)>>>(g, part, B, C, hw, batch_stride, per_slice);
     LOCATE_LAUNCH_CHECK("locate_channel_sum");
+    channel_sum_final_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(part, out, C, slices);
+    LOCATE_LAUNCH_CHECK("locate_channel_sum(final)");
     return LOCATE_OK;
 }

@@ -237,29 +237,34 @@ __global__ void __launch_bounds__(256) sn_rank1_kernel(const double* __restrict_
 // side, <G_k, W_bar> = <gy_k, conv(x_k, W_bar)> = sigma_k <gy_k, y_k - bias>, so
 //     dsigma_k = -<G_k, W_bar> / sigma_k^2 = -(1 / sigma_k) * sum_{b in k, m, p} gy[b,m,p] (y[b,m,p] - bias[m])
 // ---------------------------------------------------------------------------------------------
+#define SGD_CHUNK 4096      // elements per block visit
 __global__ void __launch_bounds__(256) sn_group_dot_kernel(const float* __restrict__ gy, int64_t gy_bs, const float* __restrict__ y,
                                                            int64_t y_bs, const float* __restrict__ bias, int Bg, int M, int plane,
                                                            double* __restrict__ partial) {
-    // blocks walk whole (batch, channel) planes: one division per plane, 16-byte loads inside
+    // One batch element is a contiguous run of M * plane values: blocks walk (batch element, 4096-element chunk) pairs
+    // with 16-byte loads; the channel (for the bias) costs one 32-bit division per four elements.
     __shared__ double scratch[16];
     const int grp = blockIdx.y;
-    const int planes = Bg * M;
+    const int per_b = M * plane;
+    const int nchunk = (per_b + SGD_CHUNK - 1) / SGD_CHUNK;
+    const int work = Bg * nchunk;
     const bool vec = (plane & 3) == 0 && (gy_bs & 3) == 0 && (y_bs & 3) == 0 && ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     double acc = 0.0;
-    for (int pl = blockIdx.x; pl < planes; pl += gridDim.x) {
-        const int bl = pl / M, m = pl - bl * M;
+    for (int w = blockIdx.x; w < work; w += gridDim.x) {
+        const int bl = w / nchunk, ch = w - bl * nchunk;
         const int64_t b = (int64_t)grp * Bg + bl;
-        const float* gp = gy + b * gy_bs + (int64_t)m * plane;
-        const float* yp = y + b * y_bs + (int64_t)m * plane;
-        const float bv = bias ? bias[m] : 0.0f;
+        const float* gp = gy + b * gy_bs;
+        const float* yp = y + b * y_bs;
+        const int j0 = ch * SGD_CHUNK, j1 = min(j0 + SGD_CHUNK, per_b);
         float part = 0.0f;
         if (vec) {
-            for (int i = threadIdx.x; i < (plane >> 2); i += blockDim.x) {
-                const float4 g4 = reinterpret_cast<const float4*>(gp)[i], y4 = reinterpret_cast<const float4*>(yp)[i];
+            for (int j = j0 + 4 * (int)threadIdx.x; j < j1; j += 1024) {
+                const float bv = bias ? bias[j / plane] : 0.0f;
+                const float4 g4 = *reinterpret_cast<const float4*>(gp + j), y4 = *reinterpret_cast<const float4*>(yp + j);
                 part += (g4.x * (y4.x - bv) + g4.y * (y4.y - bv)) + (g4.z * (y4.z - bv) + g4.w * (y4.w - bv));
             }
         } else {
-            for (int i = threadIdx.x; i < plane; i += blockDim.x) part = fmaf(gp[i], yp[i] - bv, part);
+            for (int j = j0 + (int)threadIdx.x; j < j1; j += 256) part = fmaf(gp[j], yp[j] - (bias ? bias[j / plane] : 0.0f), part);
         }
         acc += (double)part;
     }
@@ -317,7 +322,9 @@ LOCATE_API int locate_sn_weight_bwd_grouped(const float* gy, int64_t gy_bs, cons
     LOCATE_REQUIRE(!du || wv, "locate_sn_weight_bwd_grouped: du requested without the saved W v");
     hipStream_t st = as_stream(stream);
     double* partial = static_cast<double*>(workspace);
-    int nb = Bg * M < 256 ? Bg * M : 256;      // the workspace holds 4 x 256 partial sums
+    const int64_t work = (int64_t)Bg * (((int64_t)M * plane + SGD_CHUNK - 1) / SGD_CHUNK);
+    LOCATE_REQUIRE((int64_t)M * plane < (1ll << 31), "locate_sn_weight_bwd_grouped: layer output too large");
+    const int nb = work < 256 ? (int)work : 256;      // the workspace holds 4 x 256 partial sums
     sn_group_dot_kernel<<<dim3(nb, groups), 256, 0, st>>>(gy, gy_bs, y, y_bs, bias, Bg, M, plane, partial);
     LOCATE_LAUNCH_CHECK("locate_sn_weight_bwd_grouped(dot)");
     const int64_t n = (int64_t)h * wd;

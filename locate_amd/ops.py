@@ -601,7 +601,10 @@ def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, garr
 def _bias_grad(gy):
     Bn, Cn = gy.shape[0], gy.shape[1]
     gb = torch.empty(Cn, dtype=torch.float32, device=gy.device)
-    check(lib().locate_channel_sum(_p(gy), _p(gb), Bn, Cn, gy.numel() // (Bn * Cn), _bs(gy), _stream()), "locate_channel_sum")
+    L = lib()
+    hw = gy.numel() // (Bn * Cn)
+    ws = _ws(L.locate_channel_sum_workspace_bytes(Bn, Cn, hw), gy.device)
+    check(L.locate_channel_sum(_p(gy), _p(gb), Bn, Cn, hw, _bs(gy), _p(ws), _stream()), "locate_channel_sum")
     return gb
 
 
