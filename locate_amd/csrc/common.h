@@ -83,12 +83,21 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
     return t;
 }
-// RootTanh pieces shared by the element-wise kernels and the fused norm/conv epilogues (see elementwise.hip).
+// RootTanh pieces shared by the element-wise kernels and the fused norm kernels (see elementwise.hip).
+// These kernels are ALU-bound with libm's expm1f / IEEE sqrt and division (~75 instructions per element against 8-12
+// bytes of traffic), so they use the hardware approximations (v_exp_f32, v_rcp_f32, v_sqrt_f32: 1 ulp each) and a short
+// series where exp(t) - 1 would cancel: ~30 instructions, errors of a few 1e-7 relative (tests: 2e-6 against fp64).
+__device__ __forceinline__ float expm1_nonpos(float t) {          // t <= 0
+    const float series = t * (1.0f + t * (0.5f + t * (0.16666667f + t * (0.041666668f + t * (0.0083333338f +
+                         t * (0.0013888889f + t * 0.0001984127f))))));          // |t| <= 0.35: truncation < 2e-8 |t|
+    const float direct = __builtin_amdgcn_exp2f(t * 1.44269504f) - 1.0f;
+    return t > -0.35f ? series : direct;
+}
+
 __device__ __forceinline__ void tanh_sech2(float x, float& th, float& sech2) {
     const float ax = fabsf(x);
-    const float em = expm1f(-2.0f * ax);
-    const float d = 2.0f + em;
-    const float r = 1.0f / d;
+    const float em = expm1_nonpos(-2.0f * ax);
+    const float r = __builtin_amdgcn_rcpf(2.0f + em);
     th = copysignf(-em * r, x);
     sech2 = 4.0f * (1.0f + em) * r * r;
 }
@@ -96,16 +105,16 @@ __device__ __forceinline__ void tanh_sech2(float x, float& th, float& sech2) {
 __device__ __forceinline__ float roottanh_f(float x) {
     float th, s2;
     tanh_sech2(x, th, s2);
-    return sqrtf(sqrtf(fmaf(x, x, 1.0f))) * th;
+    return __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(fmaf(x, x, 1.0f))) * th;
 }
 
 __device__ __forceinline__ float roottanh_grad_f(float x, float g) {
     float th, s2;
     tanh_sech2(x, th, s2);
     const float q = fmaf(x, x, 1.0f);
-    const float r = sqrtf(sqrtf(q));          // q^(1/4)
+    const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(q));          // q^(1/4)
     const float q34 = r * r * r;              // q^(3/4)
-    return g * (2.0f * q * s2 + x * th) / (2.0f * q34);
+    return g * (2.0f * q * s2 + x * th) * (0.5f * __builtin_amdgcn_rcpf(q34));
 }
 
 #endif
