@@ -113,20 +113,22 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
     }
     x += (int64_t)grp * n;
     out += (int64_t)grp * n;
+    const float inv_s = 1.0f / s;
     const int64_t plane0 = (int64_t)grp * planes_g;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if ((hw & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x);
         float4* o4 = reinterpret_cast<float4*>(out);
-        const int hw4 = hw >> 2;
+        const unsigned hw4 = (unsigned)(hw >> 2);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
-            const int64_t p = plane0 + i / hw4;
-            const int c = (int)(p % C);
+            const int64_t p = plane0 + (unsigned)i / hw4;        // n / 4 < 2^32 (checked by the host entry): 32-bit division
+            const int c = (int)((unsigned)p % (unsigned)C);
             const float y = scale[scale_per_sample ? p : c], b = bias[c];
             const float4 v = x4[i];
             float4 o;
-            o.x = (v.x - mu) * y / s + b; o.y = (v.y - mu) * y / s + b;
-            o.z = (v.z - mu) * y / s + b; o.w = (v.w - mu) * y / s + b;
+            const float ys = y * inv_s;
+            o.x = fmaf(v.x - mu, ys, b); o.y = fmaf(v.y - mu, ys, b);
+            o.z = fmaf(v.z - mu, ys, b); o.w = fmaf(v.w - mu, ys, b);
             if (ACT) { o.x = roottanh_f(o.x); o.y = roottanh_f(o.y); o.z = roottanh_f(o.z); o.w = roottanh_f(o.w); }
             o4[i] = o;
         }
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
         const int64_t p = plane0 + i / hw;
         const int c = (int)(p % C);
         const float y = scale[scale_per_sample ? p : c];
-        const float o = (x[i] - mu) * y / s + bias[c];
+        const float o = fmaf(x[i] - mu, y * inv_s, bias[c]);
         out[i] = ACT ? roottanh_f(o) : o;
     }
 }
@@ -175,9 +177,9 @@ LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per
 //   pass 3 (element-wise):         dx = y[p] go / s_g - consts[g][0] + consts[g][1] (x - mu_g)
 // ---------------------------------------------------------------------------------------------
 template <bool ACT>
-__device__ __forceinline__ float norm_go(float xv, float gv, float mu, float s, float y, float b) {
+__device__ __forceinline__ float norm_go(float xv, float gv, float mu, float inv_s, float y, float b) {
     if (!ACT) return gv;
-    const float o = (xv - mu) * y / s + b;
+    const float o = fmaf(xv - mu, y * inv_s, b);          // the same expression as the forward's norm_apply_fused_kernel
     return roottanh_grad_f(o, gv);
 }
 
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t p = wave; p < planes; p += nwaves) {
         const int grp = (int)(p / planes_g);
-        const float mu = stats[2 * grp], sd = stats[2 * grp + 1];
+        const float mu = stats[2 * grp], inv_sd = 1.0f / stats[2 * grp + 1];
         const int64_t base = p * hw;
         const int c = (int)(p % C);
         const float y = ACT ? scale[scale_per_sample ? p : c] : 0.0f, b = ACT ? bias[c] : 0.0f;
@@ -203,15 +205,15 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
             for (int i = lane; i < (hw >> 2); i += 64) {
                 const float4 xv = x4[i];
                 float4 gv = g4[i];
-                gv.x = norm_go<ACT>(xv.x, gv.x, mu, sd, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, sd, y, b);
-                gv.z = norm_go<ACT>(xv.z, gv.z, mu, sd, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, sd, y, b);
+                gv.x = norm_go<ACT>(xv.x, gv.x, mu, inv_sd, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, inv_sd, y, b);
+                gv.z = norm_go<ACT>(xv.z, gv.z, mu, inv_sd, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, inv_sd, y, b);
                 s1 += (gv.x + gv.y) + (gv.z + gv.w);
                 s2 += ((xv.x - mu) * gv.x + (xv.y - mu) * gv.y) + ((xv.z - mu) * gv.z + (xv.w - mu) * gv.w);
             }
         } else {
             for (int i = lane; i < hw; i += 64) {
                 const float xv = x[base + i];
-                const float gv = norm_go<ACT>(xv, g[base + i], mu, sd, y, b);
+                const float gv = norm_go<ACT>(xv, g[base + i], mu, inv_sd, y, b);
                 s1 += gv;
                 s2 = fmaf(xv - mu, gv, s2);
             }
@@ -308,6 +310,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
     }
     __syncthreads();
     const float m = consts[0], k = consts[1];
+    const float inv_s = 1.0f / s;
     x += (int64_t)grp * n; g += (int64_t)grp * n; dx += (int64_t)grp * n;
     const int64_t plane0 = (int64_t)grp * planes_g;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -315,18 +318,19 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         const float4* x4 = reinterpret_cast<const float4*>(x);
         const float4* g4 = reinterpret_cast<const float4*>(g);
         float4* o4 = reinterpret_cast<float4*>(dx);
-        const int hw4 = hw >> 2;
+        const unsigned hw4 = (unsigned)(hw >> 2);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
-            const int64_t p = plane0 + i / hw4;
-            const int c = (int)(p % C);
+            const int64_t p = plane0 + (unsigned)i / hw4;        // 32-bit division (n / 4 < 2^32, checked by the host entry)
+            const int c = (int)((unsigned)p % (unsigned)C);
             const float y = scale[scale_per_sample ? p : c], b = ACT ? bias[c] : 0.0f;
             const float4 xv = x4[i];
             float4 gv = g4[i];
-            gv.x = norm_go<ACT>(xv.x, gv.x, mu, s, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, s, y, b);
-            gv.z = norm_go<ACT>(xv.z, gv.z, mu, s, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, s, y, b);
+            gv.x = norm_go<ACT>(xv.x, gv.x, mu, inv_s, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, inv_s, y, b);
+            gv.z = norm_go<ACT>(xv.z, gv.z, mu, inv_s, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, inv_s, y, b);
             float4 o;
-            o.x = y * gv.x / s - m + k * (xv.x - mu); o.y = y * gv.y / s - m + k * (xv.y - mu);
-            o.z = y * gv.z / s - m + k * (xv.z - mu); o.w = y * gv.w / s - m + k * (xv.w - mu);
+            const float ys = y * inv_s;
+            o.x = fmaf(ys, gv.x, fmaf(k, xv.x - mu, -m)); o.y = fmaf(ys, gv.y, fmaf(k, xv.y - mu, -m));
+            o.z = fmaf(ys, gv.z, fmaf(k, xv.z - mu, -m)); o.w = fmaf(ys, gv.w, fmaf(k, xv.w - mu, -m));
             o4[i] = o;
         }
         return;
@@ -335,8 +339,8 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         const int64_t p = plane0 + i / hw;
         const int c = (int)(p % C);
         const float y = scale[scale_per_sample ? p : c];
-        const float gv = norm_go<ACT>(x[i], g[i], mu, s, y, ACT ? bias[c] : 0.0f);
-        dx[i] = y * gv / s - m + k * (x[i] - mu);
+        const float gv = norm_go<ACT>(x[i], g[i], mu, inv_s, y, ACT ? bias[c] : 0.0f);
+        dx[i] = fmaf(y * inv_s, gv, fmaf(k, x[i] - mu, -m));
     }
 }
 

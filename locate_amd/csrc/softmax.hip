@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_wave_kernel(const float* __re
     float sum = 0.0f;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        v[e] = expf(v[e] - mx);   // exp(-inf) = 0 for the padding lanes
+        v[e] = __expf(v[e] - mx);   // exp(-inf) = 0 for the padding lanes
         sum += v[e];
     }
     sum = wave_sum(sum);
@@ -72,10 +72,10 @@ __global__ void __launch_bounds__(256) softmax_fwd_block_kernel(const float* __r
     for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, xr[i]);
     mx = block_max(mx, scratch);
     float sum = 0.0f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) sum += expf(xr[i] - mx);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sum += __expf(xr[i] - mx);
     sum = block_sum<float>(sum, scratch);
     const float inv = 1.0f / sum;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) yr[i] = expf(xr[i] - mx) * inv;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) yr[i] = __expf(xr[i] - mx) * inv;
 }
 
 __global__ void __launch_bounds__(256) softmax_bwd_block_kernel(const float* __restrict__ y, const float* __restrict__ g,

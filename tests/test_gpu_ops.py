@@ -252,7 +252,9 @@ def test_stacked_discriminator_pass_equals_three_calls(size, ff, B):
     for (k, a), (_, b) in zip(D1.named_parameters(), D2.named_parameters()):
         assert (a.grad is None) == (b.grad is None), k
         if a.grad is not None:
-            assert_close(b.grad.cpu(), a.grad.cpu(), 2e-4, "grad " + k)
+            # du, dv carry dsigma = -<G, W_bar> / sigma^2 (heavy cancellation, see test_spectral_norm_layers_golden) and the
+            # two paths sum <G, W_bar> in different orders (weight side vs activation side)
+            assert_close(b.grad.cpu(), a.grad.cpu(), 1e-3 if k.endswith(("weight_u", "weight_v")) else 2e-4, "grad " + k)
 
 
 # ---------------------------------------------------------------------- dense contractions vs torch CPU
