@@ -83,6 +83,20 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
     return t;
 }
+// q = i / d, r = i % d for 32-bit unsigned operands: shift/mask when d is a power of two (every spatial size and most
+// channel counts of this model), one 32-bit division otherwise.  The kernels' flat element indices stay below 2^31
+// (checked by the host entries), so none of them needs the ~100-instruction 64-bit division in its inner loop.
+struct DivU32 {
+    unsigned d, mask;
+    int shift;          // >= 0: d == 1 << shift
+    __device__ __forceinline__ explicit DivU32(unsigned dd) : d(dd), mask(dd - 1), shift((dd & (dd - 1)) == 0 ? __ffs((int)dd) - 1 : -1) {}
+    __device__ __forceinline__ void divmod(unsigned i, unsigned& q, unsigned& r) const {
+        if (shift >= 0) { q = i >> shift; r = i & mask; }
+        else { q = i / d; r = i - q * d; }
+    }
+    __device__ __forceinline__ unsigned div(unsigned i) const { return shift >= 0 ? i >> shift : i / d; }
+};
+
 // RootTanh pieces shared by the element-wise kernels and the fused norm kernels (see elementwise.hip).
 // These kernels are ALU-bound with libm's expm1f / IEEE sqrt and division (~75 instructions per element against 8-12
 // bytes of traffic), so they use the hardware approximations (v_exp_f32, v_rcp_f32, v_sqrt_f32: 1 ulp each) and a short

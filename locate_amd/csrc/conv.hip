@@ -692,16 +692,19 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 int scale_bg, int scale_stride, int B, int M, int plane,
                                                                 long long out_bs, long long slab_stride, int ksplit) {
-    const long long per_b = (long long)M * plane;
-    const long long total = (long long)B * per_b;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const long long b = i / per_b, r = i - b * per_b;
+    // flat indices stay below 2^31 (host entry): power-of-two shifts or one 32-bit division instead of 64-bit ones
+    const unsigned per_b = (unsigned)M * (unsigned)plane;
+    const unsigned total = (unsigned)B * per_b;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dpb(per_b), dpl((unsigned)plane);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        unsigned b, r;
+        dpb.divmod(i, b, r);
         float acc = 0.0f;
         for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
         if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
-        if (bias) acc += bias[(int)(r / plane)];
-        out[b * out_bs + r] = acc;
+        if (bias) acc += bias[dpl.div(r)];
+        out[(long long)b * out_bs + r] = acc;
     }
 }
 
@@ -854,6 +857,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     LOCATE_LAUNCH_CHECK(who);
     if (p.ksplit > 1) {
         const long long total = p.slab_stride;
+        LOCATE_REQUIRE(total < (1ll << 31), "%s: split-K output of %lld elements exceeds the 32-bit index range", who, total);
         igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
                                                                          p.slab_stride, p.ksplit);
         LOCATE_LAUNCH_CHECK(who);

@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__
         }
         return;
     }
+    const DivU32 dhw((unsigned)hw);          // n < 2^31 (host entry)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float av = a_per_plane ? a[i / hw] : a[i];
+        const float av = a_per_plane ? a[dhw.div((unsigned)i)] : a[i];
         out[i] = fmaf(gm, av, 1.0f) * x[i];
     }
 }
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) gate_bwd_final_kernel(const double* __res
 
 LOCATE_API int locate_gate_fwd(const float* x, const float* a, int a_per_plane, const float* gamma, float* out,
                                int64_t planes, int hw, void* stream) {
-    LOCATE_REQUIRE(planes >= 0 && hw > 0, "locate_gate_fwd: bad shape");
+    LOCATE_REQUIRE(planes >= 0 && hw > 0 && planes * hw < (1ll << 31), "locate_gate_fwd: bad shape");
     const int64_t n = planes * hw;
     if (n == 0) return LOCATE_OK;
     gate_fwd_kernel<<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, a, gamma, out, n, hw, a_per_plane);
@@ -241,14 +242,23 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) copy_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
                                                           int64_t chw, int64_t src_bs, int64_t dst_bs, int accumulate) {
-    const int64_t total = (int64_t)B * chw;
+    // one batch element per blockIdx.y: no division, 16-byte accesses when everything is aligned
+    const int b = blockIdx.y;
+    const float* s = src + (int64_t)b * src_bs;
+    float* d = dst + (int64_t)b * dst_bs;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t b = i / chw, r = i - b * chw;
-        const float v = src[b * src_bs + r];
-        float* d = dst + b * dst_bs + r;
-        *d = accumulate ? (*d + v) : v;
+    const bool vec = ((chw | src_bs | dst_bs) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (vec) {
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        float4* d4 = reinterpret_cast<float4*>(d);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (chw >> 2); i += stride) {
+            float4 v = s4[i];
+            if (accumulate) { const float4 o = d4[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            d4[i] = v;
+        }
+        return;
     }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += stride) d[i] = accumulate ? d[i] + s[i] : s[i];
 }
 
 LOCATE_API int locate_copy_channels(const float* src, float* dst, int B, int C, int hw, int64_t src_batch_stride,
@@ -257,8 +267,10 @@ LOCATE_API int locate_copy_channels(const float* src, float* dst, int B, int C, 
     const int64_t chw = (int64_t)C * hw;
     if ((int64_t)B * chw == 0) return LOCATE_OK;
     LOCATE_REQUIRE(src_batch_stride >= chw && dst_batch_stride >= chw, "locate_copy_channels: batch stride smaller than slice");
-    copy_planes_kernel<<<stream_grid((int64_t)B * chw, 256), 256, 0, as_stream(stream)>>>(src, dst, B, chw, src_batch_stride,
-                                                                                         dst_batch_stride, accumulate);
+    int gx = stream_grid(chw, 1024);
+    if (gx > 64) gx = 64;
+    copy_planes_kernel<<<dim3(gx, B), 256, 0, as_stream(stream)>>>(src, dst, B, chw, src_batch_stride, dst_batch_stride,
+                                                                   accumulate);
     LOCATE_LAUNCH_CHECK("locate_copy_channels");
     return LOCATE_OK;
 }

@@ -19,18 +19,19 @@ __device__ __forceinline__ void bil_src(int dst, int size, int& i0, int& i1, flo
 __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t planes, int H, int W) {
     const int OH = 2 * H, OW = 2 * W;
-    const int64_t n = planes * OH * OW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int ox = (int)(i % OW);
-        const int64_t t = i / OW;
-        const int oy = (int)(t % OH);
-        const int64_t p = t / OH;
+    const unsigned n = (unsigned)(planes * OH * OW);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)OW), dh((unsigned)OH);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, uox, p, uoy;
+        dw.divmod(i, t, uox);
+        dh.divmod(t, p, uoy);
+        const int ox = (int)uox, oy = (int)uoy;
         int y0, y1, x0, x1;
         float ly0, ly1, lx0, lx1;
         bil_src(oy, H, y0, y1, ly0, ly1);
         bil_src(ox, W, x0, x1, lx0, lx1);
-        const float* xp = x + p * H * W;
+        const float* xp = x + (int64_t)p * H * W;
         y[i] = ly0 * (lx0 * xp[y0 * W + x0] + lx1 * xp[y0 * W + x1]) + ly1 * (lx0 * xp[y1 * W + x0] + lx1 * xp[y1 * W + x1]);
     }
 }
@@ -49,14 +50,15 @@ __device__ __forceinline__ float bil_weight_to(int dst, int size, int target) {
 __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                              int64_t planes, int H, int W) {
     const int OH = 2 * H, OW = 2 * W;
-    const int64_t n = planes * H * W;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int ix = (int)(i % W);
-        const int64_t t = i / W;
-        const int iy = (int)(t % H);
-        const int64_t p = t / H;
-        const float* gp = gy + p * OH * OW;
+    const unsigned n = (unsigned)(planes * H * W);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)W), dh((unsigned)H);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, uix, p, uiy;
+        dw.divmod(i, t, uix);
+        dh.divmod(t, p, uiy);
+        const int ix = (int)uix, iy = (int)uiy;
+        const float* gp = gy + (int64_t)p * OH * OW;
         float wy[4], wx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -84,14 +86,14 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __rest
 __global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
                                                            int H, int W) {
     const int OH = H / 2, OW = W / 2;
-    const int64_t n = planes * OH * OW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int ox = (int)(i % OW);
-        const int64_t t = i / OW;
-        const int oy = (int)(t % OH);
-        const int64_t p = t / OH;
-        const float* xp = x + p * H * W + (2 * oy) * W + 2 * ox;
+    const unsigned n = (unsigned)(planes * OH * OW);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)OW), dh((unsigned)OH);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, ox, p, oy;
+        dw.divmod(i, t, ox);
+        dh.divmod(t, p, oy);
+        const float* xp = x + (int64_t)p * H * W + (2 * oy) * W + 2 * ox;
         y[i] = ((xp[0] + xp[1]) + (xp[W] + xp[W + 1])) * 0.25f;
     }
 }
@@ -99,15 +101,15 @@ __global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restri
 __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                            int64_t planes, int H, int W) {
     const int OH = H / 2, OW = W / 2;
-    const int64_t n = planes * H * W;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int ix = (int)(i % W);
-        const int64_t t = i / W;
-        const int iy = (int)(t % H);
-        const int64_t p = t / H;
-        const int oy = iy >> 1, ox = ix >> 1;
-        gx[i] = (oy < OH && ox < OW) ? gy[p * OH * OW + oy * OW + ox] * 0.25f : 0.0f;
+    const unsigned n = (unsigned)(planes * H * W);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)W), dh((unsigned)H);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, ix, p, iy;
+        dw.divmod(i, t, ix);
+        dh.divmod(t, p, iy);
+        const int oy = (int)(iy >> 1), ox = (int)(ix >> 1);
+        gx[i] = (oy < OH && ox < OW) ? gy[(int64_t)p * OH * OW + oy * OW + ox] * 0.25f : 0.0f;
     }
 }
 
@@ -126,14 +128,20 @@ __global__ void __launch_bounds__(256) feature_pool_fwd_kernel(const float* __re
 
 __global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                int64_t n_out, int r) {
-    const int64_t n = n_out * r;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gx[i] = gy[i / r] / (float)r;
+    const unsigned n = (unsigned)(n_out * r);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dr((unsigned)r);
+    const bool pow2 = dr.shift >= 0;
+    const float inv = 1.0f / (float)r;         // exact for powers of two; other ratios keep the division (same rounding as ATen)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = gy[dr.div(i)];
+        gx[i] = pow2 ? g * inv : g / (float)r;
+    }
 }
 
 #define RESAMPLE_ENTRY(NAME, KERNEL, WORK)                                                                       \
     LOCATE_API int NAME(const float* a, float* b, int64_t planes, int H, int W, void* stream) {                  \
-        LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0, #NAME ": bad shape");                                       \
+        LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), #NAME ": bad shape");   \
         KERNEL<<<stream_grid((WORK), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);                     \
         LOCATE_LAUNCH_CHECK(#NAME);                                                                              \
         return LOCATE_OK;                                                                                        \
@@ -156,7 +164,7 @@ LOCATE_API int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, 
 }
 
 LOCATE_API int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, void* stream) {
-    LOCATE_REQUIRE(n_out > 0 && r > 0, "locate_feature_pool_bwd: bad shape");
+    LOCATE_REQUIRE(n_out > 0 && r > 0 && n_out * r < (1ll << 31), "locate_feature_pool_bwd: bad shape");
     feature_pool_bwd_kernel<<<stream_grid(n_out * r, 256), 256, 0, as_stream(stream)>>>(gy, gx, n_out, r);
     LOCATE_LAUNCH_CHECK("locate_feature_pool_bwd");
     return LOCATE_OK;
