@@ -153,7 +153,7 @@ LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per
     LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_fwd: bad group count %d for batch %d", groups, B);
     LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_fwd: x must be 16-byte aligned");
     const int64_t planes_g = (int64_t)(B / groups) * C, n_g = planes_g * hw;
-    LOCATE_REQUIRE(n_g > 1, "locate_norm_fwd: needs at least two elements per group");
+    LOCATE_REQUIRE(n_g > 1 && n_g < (1ll << 33), "locate_norm_fwd: needs 2 .. 2^33 elements per group");
     LOCATE_REQUIRE(groups == 1 || (n_g & 3) == 0, "locate_norm_fwd: grouped tensors need a group size that is a multiple of 4");
     int np = stream_grid(n_g, 256 * 16);
     if (np > NORM_MAX_PARTIALS) np = NORM_MAX_PARTIALS;
@@ -358,6 +358,7 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd: bad shape or missing workspace");
     LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_bwd: bad group count");
     LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd: with_act needs the bias");
+    LOCATE_REQUIRE((int64_t)B * C / groups * hw < (1ll << 33), "locate_norm_bwd: more than 2^33 elements per group");
     const int64_t planes = (int64_t)B * C, planes_g = planes / groups;
     LOCATE_REQUIRE(groups == 1 || ((planes_g * hw) & 3) == 0, "locate_norm_bwd: grouped tensors need a group size that is a multiple of 4");
     const int nfb = (C + NF_CH - 1) / NF_CH;
