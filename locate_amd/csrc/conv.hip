@@ -1326,11 +1326,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
 // ---------------------------------------------------------------------------------------------
 // The weight gradient on the bf16 matrix cores with exact three-way splits (see conv_igemm_bx6_kernel).  The reduction
 // index n = (b, oh, ow) is the MFMA's k: every thread loads PAIRS of adjacent n (coalesced along n), splits them and
-// writes the packed bf16 pairs to LDS images [piece][row][n] (n contiguous, 48-byte row pitch: conflict-free
-// ds_read_b128 fragments of 8 consecutive n).  Needs even OH*OW and OW (a pair never straddles an image or a row).
+// writes the packed bf16 pairs to LDS images [piece][row][n] (n contiguous, 32-byte rows with an XOR swizzle of the two
+// halves: conflict-free ds_read_b128 fragments of 8 consecutive n; 48 KiB per block, three blocks per CU).  Needs even OH*OW and OW (a pair never straddles an image or a row).
 // ---------------------------------------------------------------------------------------------
 #define WB_BK 16                      // reduction elements per stage = one MFMA k
-#define WB_PITCH 12                   // dwords per LDS row: 8 (16 bf16) + 4 padding
+#define WB_PITCH 8                    // dwords per LDS row (16 bf16, no padding): the two 16-byte halves of a row are
+                                      // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
+                                      // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
 __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -1345,7 +1347,7 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, uns
 }
 
 template <int WGM, int WGN, int TM, int TN>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_bx6_kernel(const WgParams p) {
+__global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BR = WGN * TN * 32;
     constexpr int G_PT = BM / 32;          // row groups per thread: rows sub + 32 i
@@ -1438,27 +1440,30 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bx6_kernel(const WgParams p
             xreg[i].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(v1 ? o + 4u * (unsigned)p.stride : 0x80000000u), 0, 0));
         }
     };
+    // dword column of this thread's pair inside its rows: rows sub + 32 i all have bit 3 of `sub`
+    const int wcol = (((np >> 2) ^ ((sub >> 3) & 1)) << 2) | (np & 3);
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
             unsigned h, m, l;
             split3_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
-            Gs[buf][0][sub + 32 * i][np] = h;
-            Gs[buf][1][sub + 32 * i][np] = m;
-            Gs[buf][2][sub + 32 * i][np] = l;
+            Gs[buf][0][sub + 32 * i][wcol] = h;
+            Gs[buf][1][sub + 32 * i][wcol] = m;
+            Gs[buf][2][sub + 32 * i][wcol] = l;
         }
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
             unsigned h, m, l;
             split3_pair(xreg[i].x, xreg[i].y, h, m, l);
-            Xs[buf][0][sub + 32 * i][np] = h;
-            Xs[buf][1][sub + 32 * i][np] = m;
-            Xs[buf][2][sub + 32 * i][np] = l;
+            Xs[buf][0][sub + 32 * i][wcol] = h;
+            Xs[buf][1][sub + 32 * i][wcol] = m;
+            Xs[buf][2][sub + 32 * i][wcol] = l;
         }
     };
 
     const int nsteps = (n_end - n_begin + WB_BK - 1) / WB_BK;
     const int lrow = lane >> 5, lcol = lane & 31;
+    const int rhalf = lrow ^ ((lcol >> 3) & 1);          // fragment rows are tile_row0 + lcol with tile_row0 % 32 == 0
     if (nsteps > 0) {
         load_tiles(n_begin);
         store_tiles(0);
@@ -1472,11 +1477,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bx6_kernel(const WgParams p
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][lrow * 4]);
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][lrow * 4]);
+            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
