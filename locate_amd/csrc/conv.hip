@@ -1544,12 +1544,21 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     const int R = g.C * g.KH * g.KW;
     const int64_t N = (int64_t)g.B * g.OH * g.OW;
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
-    int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks (256 CUs x 2 resident x 2 rounds)
-    const int64_t max_split = (N + 255) / 256;           // at least 256 reduction elements per block
-    if (want > max_split) want = max_split;
-    if (want > 512) want = 512;
-    if (want < 1) want = 1;
-    int64_t ch = (N + want - 1) / want;
+    // Split the reduction over s blocks per tile so that the launch fills whole rounds of the 768 resident blocks
+    // (256 CUs x 3): cost(s) = rounds(s) x reduction elements per block, plus the slab traffic of s > 1 expressed in
+    // the same unit (one output tile written and re-read ~ 96 reduction elements of MFMA time).
+    const int64_t max_split = N >= 512 ? N / 256 : 1;     // at least 256 reduction elements per block
+    int64_t best_s = 1;
+    double best_cost = 1e300;
+    for (int64_t s_ = 1; s_ <= max_split && s_ <= 512; ++s_) {
+        int64_t ch = (N + s_ - 1) / s_;
+        ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
+        const int64_t ns = (N + ch - 1) / ch;
+        const int64_t rounds = (tiles * ns + 767) / 768;
+        const double cost = (double)rounds * (double)ch + (ns > 1 ? 96.0 * (double)ns * (double)tiles / 768.0 : 0.0);
+        if (cost < best_cost * 0.999) { best_cost = cost; best_s = s_; }
+    }
+    int64_t ch = (N + best_s - 1) / best_s;
     ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
     *chunk = (int)ch;
     *nsplit = (int)((N + ch - 1) / ch);
