@@ -821,7 +821,11 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     if (tiles >= 768 || (tiles >= 512 && tiles % 256 == 0)) return 1;
     const int steps = min_kpad / IG_BK;
     long long want = (768 + tiles - 1) / tiles;
-    const int max_split = steps / 8 > 0 ? steps / 8 : 1;      // at least 8 K steps (128 reduction elements) per block
+    // at least 8 K steps (128 reduction elements) per block - 2 when the output is tiny (the style linears, the deep
+    // discriminator layers at batch-sized N): those launches are a latency chain of K steps on a handful of blocks and
+    // their partial tiles cost next to nothing
+    const int min_steps = (long long)M * nmax <= (1 << 16) ? 2 : 8;
+    const int max_split = steps / min_steps > 0 ? steps / min_steps : 1;
     if (want > max_split) want = max_split;
     if (want > 64) want = 64;
     return want < 1 ? 1 : (int)want;
