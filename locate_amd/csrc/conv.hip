@@ -325,21 +325,35 @@ struct IgParams {
 
 // Shared epilogue of the implicit-GEMM kernels (both MFMA flavours have the same 32x32 accumulator layout).
 template <int WGM, int WGN, int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN], int N, int n0,
-                                               int m0, int zsplit, int wm, int wn, int lane) {
+__device__ __forceinline__ void igemm_col_scales(const IgParams& p, const IgPhase& ph, float (&col_scale)[TN], int N, int n0,
+                                                 int wn, int lane) {
+    // 1/sigma of each of this lane's output columns (the batch may stack several forwards).  Loaded BEFORE the K loop:
+    // at its end it would be one more dependent memory round trip on the critical path of every block.
+    const int lcol = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nj = n0 + (wn * TN + j) * 32 + lcol;
+        const int nn = nj < N ? nj : 0;
+        const int b = nn / (ph.QH * ph.QW);
+        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN],
+                                               const float (&col_scale)[TN], int N, int n0, int m0, int zsplit, int wm,
+                                               int wn, int lane) {
     const int lrow = lane >> 5, lcol = lane & 31;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
     const bool split = p.ksplit > 1;
     const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
-    float col_scale[TN];           // 1/sigma of the column's group (the batch may stack several forwards)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nj = n0 + (wn * TN + j) * 32 + lcol;
         const int nn = nj < N ? nj : 0;
         const int qhw = ph.QH * ph.QW;
         const int b = nn / qhw, q = nn - b * qhw;
-        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
         const int qy = q / ph.QW, qx = q - qy * ph.QW;
         const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
         const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
@@ -458,6 +472,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     const int ncol = tid % BN;
     const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform
     const GatherCol gc = gather_setup(p, ph, n0 + ncol, N);
+    float col_scale[TN];
+    igemm_col_scales<WGM, WGN, TM, TN>(p, ph, col_scale, N, n0, wn, lane);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,6 +608,8 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     const int ncol = tid % BN;
     const int kgrp = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform k-block of this thread's fragment
     const GatherCol gc = gather_setup(p, ph, n0 + ncol, N);
+    float col_scale[TN];
+    igemm_col_scales<WGM, WGN, TM, TN>(p, ph, col_scale, N, n0, wn, lane);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -684,7 +702,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         store_tiles(buf ^ 1);
         __syncthreads();
     }
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, N, n0, m0, zsplit, wm, wn, lane);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane);
 }
 
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
