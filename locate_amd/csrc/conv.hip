@@ -637,16 +637,20 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
 
     uint4 areg[3];
     float breg[8];
+    // the offset-table rows are fetched one stage ahead of the gather that uses them: the scalar load's round trip is
+    // then off the per-stage critical path (it used to sit in front of every stage's buffer loads)
+    i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + __builtin_amdgcn_readfirstlane(kidx));                       // s_load_dwordx8
+    unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + __builtin_amdgcn_readfirstlane(kidx));   // s_load_dwordx2
     auto issue_loads = [&]() {
 #pragma unroll
         for (int q = 0; q < 3; ++q) areg[q] = ap[q * a_plane];
         ap += a_step;
-        const int ks = __builtin_amdgcn_readfirstlane(kidx);
-        const i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + ks);                        // s_load_dwordx8
-        const unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + ks);   // s_load_dwordx2
 #pragma unroll
         for (int j = 0; j < 8; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
         kidx += BK;
+        const int ks = __builtin_amdgcn_readfirstlane(kidx);
+        offs = *reinterpret_cast<const i32x8*>(ph.koff + ks);
+        taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + ks);
     };
     auto store_tiles = [&](int buf) {
         if (a_thread) {
