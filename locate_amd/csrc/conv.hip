@@ -342,11 +342,56 @@ __device__ __forceinline__ void igemm_col_scales(const IgParams& p, const IgPhas
 template <int WGM, int WGN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN],
                                                const float (&col_scale)[TN], int N, int n0, int m0, int zsplit, int wm,
-                                               int wn, int lane) {
+                                               int wn, int lane, float* stage) {
     const int lrow = lane >> 5, lcol = lane & 31;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
     const bool split = p.ksplit > 1;
+    // Small output planes (linears and the deep layers: 1x1 ... 4x4 maps): the lanes of an accumulator register hold 32
+    // different columns n = (b, pixel), whose addresses are a whole channel stack apart - 64 scattered 4-byte stores per
+    // instruction (measured: 5-11 us of a 10 us launch).  There the 32x32 tile goes through a wave-private LDS patch and
+    // is written out along (m, pixel), which is contiguous inside one batch element.
+    const int iplane = (int)plane;
+    if (stage != nullptr && p.nphase == 1 && p.ostep == 1 && iplane <= 16 && (iplane & (iplane - 1)) == 0 &&
+        ph.QH * ph.QW == iplane) {
+        const int lp = __ffs(iplane) - 1;
+        float* out_base = split ? p.slab + (long long)zsplit * p.slab_stride : p.out;
+        const long long obs = split ? (long long)p.M * plane : p.out_bs;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mt0 = m0 + (wm * TM + i) * 32;
+            float bias_v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt0 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const bool use = p.bias != nullptr && !split && m < p.M;
+                const float* bp = use ? p.bias + m : p.in;
+                bias_v[r] = use ? *bp : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nt0 = n0 + (wn * TN + j) * 32;          // multiple of 32, hence of the plane size
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                    stage[lcol * 33 + ml] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const int b0 = nt0 >> lp;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int flat = e * 64 + lane;
+                    const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
+                    const int ml = rem >> lp, pix = rem & (iplane - 1);
+                    const int nl = (bl << lp) + pix;
+                    const float v = stage[nl * 33 + ml];
+                    if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+        }
+        return;
+    }
     const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -566,7 +611,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -706,7 +751,9 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         store_tiles(buf ^ 1);
         __syncthreads();
     }
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane);
+    // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane,
+                                     reinterpret_cast<float*>(&Bs[0][0][0][0]) + wid * (32 * 33));   // Bs: 24 KiB for every tile shape
 }
 
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
