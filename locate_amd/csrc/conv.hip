@@ -894,6 +894,7 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     // discriminator layers at batch-sized N): those launches are a latency chain of K steps on a handful of blocks and
     // their partial tiles cost next to nothing
     const int min_steps = (long long)M * nmax <= (1 << 16) ? 2 : 8;
+    if (steps < 8) return 1;                                   // a K step of a lone block is ~1.2 us, the reduction launch ~3
     const int max_split = steps / min_steps > 0 ? steps / min_steps : 1;
     if (want > max_split) want = max_split;
     if (want > 64) want = 64;
