@@ -35,6 +35,8 @@ def parse():
                     help="run the three discriminator passes of the D-step on three streams (measured: no gain under "
                          "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="replay the G-step's generator pass in line instead of on a second stream beside the D-step")
     return ap.parse_args()
 
 
@@ -158,7 +160,7 @@ def main():
     aug = torch.randn(B, 3, S, S, generator=gen).clamp(-1, 1).to(dev)
 
     use_graph = not args.no_graph
-    runner = GraphedTrainStep(step, latent, real, aug, warmup=2) if use_graph else None
+    runner = GraphedTrainStep(step, latent, real, aug, warmup=2, overlap=False if args.no_overlap else None) if use_graph else None
 
     def one_step():
         if runner is not None:

@@ -11,8 +11,15 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, step, latent, real, aug, warmup=2):
+    def __init__(self, step, latent, real, aug, warmup=2, overlap=None):
+        """overlap (default: on for minibatches == 1 without the three-stream D-step): the iteration is captured as SIX
+        graphs - D-step generator pass | D forward/backward | D Nadam | G-step generator pass | D(fake) + backward | G
+        Nadam - and the G-step's generator pass is replayed on a second stream as soon as the D-step's generator pass is
+        done: it reads nothing the D-step writes (G's weights, panels and spectral-norm state only), and most kernels of
+        both chains are too small to fill the chip on their own.  It gets a memory pool of its own, because graphs that
+        run concurrently must not share recycled allocations."""
         self.step = step
+        self.overlap = (step.minibatches == 1 and not step.concurrent_d) if overlap is None else bool(overlap)
         self.inputs = tuple(t.clone() for t in (latent, real, aug))
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -31,25 +38,41 @@ class GraphedTrainStep:
         self.graphs = []
         self.outputs = {}
 
-        def capture(fn):
+        cap_stream = torch.cuda.Stream()     # ONE capture stream: autograd replays a node's backward on its forward's stream
+        self.pool_b = torch.cuda.graph_pool_handle()
+        self._side = torch.cuda.Stream()
+        self._e1, self._e2 = torch.cuda.Event(), torch.cuda.Event()
+
+        def capture(fn, pool=None):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool):
+            with torch.cuda.graph(g, pool=pool or self.pool, stream=cap_stream):
                 out = fn()
             self.graphs.append(g)
-            if out:
+            if isinstance(out, dict):
                 self.outputs.update(out)
+            return out
 
         # data parallel: the collectives stay OUTSIDE the graphs (replay: backward graph -> eager bucketed all-reduce ->
         # optimizer graph), so nothing RCCL-related is ever captured
         self.reducers = (step.reducer_d, step.reducer_g)
         step.reducer_d = step.reducer_g = None
         try:
-            capture(lambda: step.d_forward_backward(lat, real_, aug_))
-            self._prime(step.dis_opt)
-            capture(step.d_optimizer)
-            capture(lambda: step.g_forward_backward(lat))
-            self._prime(step.gen_opt)
-            capture(step.g_optimizer)
+            if self.overlap:
+                generated = capture(lambda: step.d_generate(lat))                              # 0
+                capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1
+                self._prime(step.dis_opt)
+                capture(step.d_optimizer)                                                      # 2
+                fake = capture(lambda: step.g_forward(lat), pool=self.pool_b)                  # 3 (second stream)
+                capture(lambda: step.g_backward(fake))                                         # 4
+                self._prime(step.gen_opt)
+                capture(step.g_optimizer)                                                      # 5
+            else:
+                capture(lambda: step.d_forward_backward(lat, real_, aug_))
+                self._prime(step.dis_opt)
+                capture(step.d_optimizer)
+                capture(lambda: step.g_forward_backward(lat))
+                self._prime(step.gen_opt)
+                capture(step.g_optimizer)
         finally:
             step.reducer_d, step.reducer_g = self.reducers
 
@@ -67,14 +90,33 @@ class GraphedTrainStep:
             if src is not None:
                 dst.copy_(src)
         red_d, red_g = self.reducers
-        self.graphs[0].replay()
-        if red_d is not None:
-            red_d.reduce_now()
-        self.graphs[1].replay()
-        self.graphs[2].replay()
-        if red_g is not None:
-            red_g.reduce_now()
-        self.graphs[3].replay()
+        if self.overlap:
+            main = torch.cuda.current_stream()
+            g = self.graphs
+            g[0].replay()                          # D-step generator pass
+            self._e1.record(main)
+            self._side.wait_event(self._e1)
+            with torch.cuda.stream(self._side):
+                g[3].replay()                      # G-step generator pass, concurrent with the discriminator work below
+                self._e2.record(self._side)
+            g[1].replay()
+            if red_d is not None:
+                red_d.reduce_now()
+            g[2].replay()
+            main.wait_event(self._e2)
+            g[4].replay()
+            if red_g is not None:
+                red_g.reduce_now()
+            g[5].replay()
+        else:
+            self.graphs[0].replay()
+            if red_d is not None:
+                red_d.reduce_now()
+            self.graphs[1].replay()
+            self.graphs[2].replay()
+            if red_g is not None:
+                red_g.reduce_now()
+            self.graphs[3].replay()
         # the replayed optimizer kernels changed the weights behind Python's back: bump the version counters so
         # that any later EAGER use (sampling, evaluation) re-packs its weight panels instead of trusting the cache
         torch._C._increment_version(self._params)

@@ -92,12 +92,18 @@ class TrainStep:
             t_.record_stream(main)
         return generated, d_true, d_fake, d_aug
 
-    def d_forward_backward(self, latent, real, aug):
+    def d_generate(self, latent):
+        """main.py:146: the D-step's generator pass (the reference builds a graph and drops it with .detach())."""
+        with torch.no_grad():
+            return self.gen(latent)
+
+    def d_forward_backward(self, latent, real, aug, generated=None):
+        """`generated`: result of d_generate(latent) when that phase ran on its own (graph.py), else computed here."""
         gen, dis = self.gen, self.dis
         dis.zero_grad()                            # main.py:148
         if self.stacked_d and getattr(dis, "batched_spectral_norm", False):
-            with torch.no_grad():
-                generated = gen(latent)
+            if generated is None:
+                generated = self.d_generate(latent)
             B = real.shape[0]
             d_all = dis(torch.cat([real, generated, aug], dim=0), stacked=3)   # :149, :150, grad_penalty.py:2 in one pass
             d_true, d_fake, d_aug = d_all[:B], d_all[B:2 * B], d_all[2 * B:]
@@ -112,8 +118,8 @@ class TrainStep:
         if self.concurrent_d:
             generated, d_true, d_fake, d_aug = self._d_forwards_concurrent(latent, real, aug)
         else:
-            with torch.no_grad():                  # main.py:146 builds a graph and drops it (.detach()); same values
-                generated = gen(latent)
+            if generated is None:
+                generated = self.d_generate(latent)
             d_true = dis(real)                     # :149
             d_fake = dis(generated)                # :150 (the reference negates it; the loss kernel takes it raw)
             d_aug = dis(aug)                       # grad_penalty.py:2
@@ -151,6 +157,27 @@ class TrainStep:
                     self.reducer_g.finish()
         finally:
             dis.requires_grad_(True)               # :172 (u, v included; the reference does it after GEN_OPTIM.step())
+        return {"g_error": loss[0], "fake": fake.detach()}
+
+    # the G-step in two phases (minibatches == 1): its generator pass depends on nothing the D-step changes, so graph.py
+    # replays it on a second stream while the D-step's discriminator work is still running
+    def g_forward(self, latent):
+        self.gen.zero_grad()                       # main.py:163
+        return self.gen(latent)
+
+    def g_backward(self, fake):
+        dis = self.dis
+        dis.requires_grad_(False)                  # main.py:161
+        try:
+            d_out = dis(fake)
+            loss, g = g_loss(d_out)
+            if self.reducer_g is not None:
+                self.reducer_g.begin()
+            d_out.backward(g.view_as(d_out))       # :169
+            if self.reducer_g is not None:
+                self.reducer_g.finish()
+        finally:
+            dis.requires_grad_(True)               # :172
         return {"g_error": loss[0], "fake": fake.detach()}
 
     def g_optimizer(self):
