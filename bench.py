@@ -205,7 +205,8 @@ def main():
             "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (BASELINE.json configs[1]), "
                                    "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
-                       "launch": ("hipGraph replay" + (" + eager RCCL all-reduce between graphs" if world > 1 else ""))
+                       "launch": ("hipGraph replay" + ("" if args.no_overlap else ", G-step generator pass on a second stream")
+                                  + (" + eager RCCL all-reduce between graphs" if world > 1 else ""))
                                  if use_graph else "eager (all-reduce overlapped with backward)"},
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }

@@ -13,7 +13,7 @@ G.batched_spectral_norm = D.batched_spectral_norm = True
 step = TrainStep(G, D, GO, DO)
 B, S = 64, 64
 lat = torch.randn(B, S, device=dev); real = torch.randn(B, 3, S, S, device=dev).clamp(-1, 1); aug = torch.randn(B, 3, S, S, device=dev).clamp(-1, 1)
-r = GraphedTrainStep(step, lat, real, aug)
+r = GraphedTrainStep(step, lat, real, aug, overlap=False)      # the four-graph (in-line) schedule, one phase per graph
 for _ in range(3): r.replay()
 torch.cuda.synchronize()
 names = ["D fwd x3 + G fwd + bwd", "D nadam", "G fwd + D fwd + bwd", "G nadam"]
