@@ -504,3 +504,73 @@ def test_loss_kernels():
         loss, g = g_loss(f.to(dev()))
         assert_close(loss.cpu(), ge.detach().reshape(1), 2e-6)
         assert_close(g.cpu(), fr2.grad, 1e-6)
+
+
+# ---------------------------------------------------------------------- bf16 x 6 vs the fp32-input MFMA kernels
+_XCHECK = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from locate_amd import ops
+dev = torch.device("cuda:0")
+out = {}
+for idx, (kind, cin, cout, k, s, p, B, H, W) in enumerate([("conv", 48, 64, 5, 2, 2, 8, 32, 32), ("convT", 192, 192, 4, 2, 1, 8, 8, 8),
+                                                          ("conv", 96, 96, 3, 1, 1, 4, 16, 16)]):
+    torch.manual_seed(100 + idx)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w = (torch.randn(wshape) * 0.1).to(dev).requires_grad_(True)
+    x = torch.randn(B, cin, H, W).to(dev).requires_grad_(True)
+    h = wshape[0]
+    u, v = torch.randn(h, device=dev), torch.randn(w.numel() // h, device=dev)
+    sigma, wv = torch.tensor([1.0, 1.0], device=dev), torch.zeros(h, device=dev)
+    y = ops.SNConvFn.apply(x, w, u, v, None, sigma, wv, ops.ConvSpec(kind, k, k, s, p, p))
+    torch.manual_seed(200 + idx)
+    y.backward(torch.randn(y.shape).to(dev))
+    out["y%%d" %% idx], out["dx%%d" %% idx], out["dw%%d" %% idx] = y.detach().cpu(), x.grad.cpu(), w.grad.cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_bf16x6_kernels_match_fp32_mfma_kernels(tmp_path):
+    """The default contractions (exact three-way bf16 splits, six bf16 MFMAs) against the fp32-input MFMA kernels kept
+    in the library as the cross-check (LOCATE_DISABLE=bx6,wbx6, read once per process - hence the two child processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("bx6", {}), ("f32", {"LOCATE_DISABLE": "bx6,wbx6"})):
+        path = str(tmp_path / (tag + ".pt"))
+        subprocess.check_call([sys.executable, "-c", _XCHECK % root, path], env=dict(os.environ, **env))
+        res[tag] = torch.load(path, weights_only=True)
+    for k in res["f32"]:
+        assert_close(res["bx6"][k], res["f32"][k], 3e-6 if k.startswith("y") or k.startswith("dx") else 3e-5, k)
+
+
+@pytest.mark.parametrize("C,size", [(768, 4), (96, 32)])
+def test_conv_stage_linearity_at_benchmark_size(C, size):
+    """Size-independent property at BASELINE's full sizes (batch 64): the ConvTranspose 4x4 s2 stage is linear in its
+    input and in its weight - f(x1 + x2) = f(x1) + f(x2), f(a x) = a f(x), and the weight gradient of a sum of output
+    gradients is the sum of the weight gradients."""
+    from locate_amd import ops
+    torch.manual_seed(C)
+    B = 64
+    w = (torch.randn(C, C, 4, 4, device=dev()) * 0.02).requires_grad_(True)
+    u, v = torch.randn(C, device=dev()), torch.randn(C * 16, device=dev())
+    sigma, wv = torch.tensor([2.0, 0.5], device=dev()), torch.zeros(C, device=dev())
+    spec = ops.ConvSpec("convT", 4, 4, 2, 1, 1)
+    x1, x2 = torch.randn(B, C, size, size, device=dev()), torch.randn(B, C, size, size, device=dev())
+
+    def f(x):
+        return ops.SNConvFn.apply(x, w, u, v, None, sigma, wv, spec)
+    with torch.no_grad():
+        y1, y2, y12, y3 = f(x1), f(x2), f(x1 + x2), f(3.0 * x1)
+    assert_close(y12.cpu(), (y1 + y2).cpu(), 3e-6, "additivity")
+    assert_close(y3.cpu(), (3.0 * y1).cpu(), 3e-6, "homogeneity")
+    g1, g2 = torch.randn_like(y1), torch.randn_like(y1)
+    grads = []
+    for g in (g1, g2, g1 + g2):
+        w.grad = None
+        f(x1).backward(g)
+        # (the rank-1 spectral-norm term dsigma u v^T is linear in g as well)
+        grads.append(w.grad.clone())
+    assert_close(grads[2].cpu(), (grads[0] + grads[1]).cpu(), 2e-5, "weight-gradient additivity")
