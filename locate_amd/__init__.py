@@ -8,4 +8,4 @@ from .nn import (ActivatedBaseConv, Block, BlockBlock, CatModule, DeepResidualCo
                  SpectralNorm, feature_attention)
 from .models import Discriminator, Generator, get_model, init, parameter_count  # noqa: F401
 from .optim import Nadam  # noqa: F401
-from .train import TrainStep  # noqa: F401
+from .train import TrainLoop, TrainStep  # noqa: F401

@@ -198,3 +198,32 @@ class TrainStep:
         out = self.d_step(latent, real, aug)
         out.update(self.g_step(latent))
         return out
+
+
+class TrainLoop:
+    """The reference's batch schedule around the step (main.py:139-172), quirks included:
+      * every batch i = 1, 2, ... runs the D-step's forward/backward with `dis.zero_grad()` first - so with
+        `miniter` > 1 the discriminator optimizer, which only steps when i % miniter == 0, sees the gradients of the
+        LAST batch only (nothing accumulates);
+      * the G-step (MINIBATCHES passes on the same noise, `gen.zero_grad()` inside the loop, then one optimizer step)
+        follows every `diters`-th discriminator step: (i // miniter) % diters == 0;
+      * `minibatch_function(epoch) = (epoch + 1) * MINIBATCHES` gives the reference's `miniter` per epoch
+        (libs/config.py:20-30); BASELINE's metric uses miniter = MINIBATCHES = DITERS = 1."""
+
+    def __init__(self, step, miniter=1, diters=1):
+        if miniter < 1 or diters < 1:
+            raise ValueError("miniter and diters must be >= 1")
+        self.step, self.miniter, self.diters = step, int(miniter), int(diters)
+        self.i = 0
+
+    def iteration(self, latent, real, aug):
+        """One batch of the loop; returns the D-step record, plus the G-step record when one ran."""
+        self.i += 1
+        i, step = self.i, self.step
+        out = step.d_forward_backward(latent, real, aug)          # main.py:146-156
+        if i % self.miniter == 0:                                  # :158
+            step.d_optimizer()                                     # :159
+            if (i // self.miniter) % self.diters == 0:             # :160
+                out.update(step.g_forward_backward(latent))        # :161-169
+                step.g_optimizer()                                 # :171
+        return out

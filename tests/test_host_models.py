@@ -92,3 +92,43 @@ def test_noise_follows_module_moves():
     G = Generator(NetConfig(image_size=32, base_feature_factor=1))
     G = G.double()
     assert G.noise.dtype == torch.float64
+
+
+@pytest.mark.parametrize("miniter,diters", [(1, 1), (2, 1), (3, 2), (8, 1)])
+def test_train_loop_schedule_matches_reference_loop(miniter, diters):
+    """TrainLoop against a literal restatement of the reference's loop body (main.py:146-172): which phases run on
+    which batch, in which order."""
+    from locate_amd import TrainLoop
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def d_forward_backward(self, latent, real, aug):
+            self.calls.append(("d_fb", latent))
+            return {"d": latent}
+
+        def d_optimizer(self):
+            self.calls.append(("d_opt",))
+
+        def g_forward_backward(self, latent):
+            self.calls.append(("g_fb", latent))
+            return {"g": latent}
+
+        def g_optimizer(self):
+            self.calls.append(("g_opt",))
+
+    rec = Recorder()
+    loop = TrainLoop(rec, miniter=miniter, diters=diters)
+    want = []
+    for i in range(1, 20):
+        out = loop.iteration(i, None, None)
+        want.append(("d_fb", i))                       # gen(noise).detach(), dis.zero_grad(), three D passes, backward
+        ran_g = False
+        if i % miniter == 0:
+            want.append(("d_opt",))
+            if (i // miniter) % diters == 0:
+                want += [("g_fb", i), ("g_opt",)]
+                ran_g = True
+        assert ("g" in out) == ran_g and out["d"] == i
+    assert rec.calls == want
