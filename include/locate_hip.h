@@ -143,6 +143,36 @@ int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
                       double* inner_partial, void* workspace, void* stream);
 
+/* ---- grouped convolutions of the SEPARABLE switch (libs/config.py:53; replaces the torch.nn.Conv2d /
+ *      ConvTranspose2d(groups = ...) forward + autograd backward under libs/conv.py:14-18 and libs/attention.py:15-21).
+ *      Depthwise: geom as above describes the REGULAR depthwise conv R between a "big" side [B, C, H, W] and a "small"
+ *      side [B, M, OH, OW]; the side with more channels has one weight row [KH*KW] per channel, the other side has
+ *      1/mult as many channels (channel o of the wide side pairs with channel o / mult of the narrow side):
+ *        Conv2d(C, C*mult, groups=C)           forward = dwconv_fwd   (M = C*mult), input gradient = dwconv_dgrad
+ *        ConvTranspose2d(M, M*mult, groups=M)  forward = dwconv_dgrad (C = M*mult), input gradient = dwconv_fwd
+ *      w is the layer's weight tensor as stored (no packing).  scale / scale_group_batch / scale_stride as in locate_conv_fwd. ---- */
+int locate_dwconv_fwd(const int* geom, const float* x, int64_t x_bs, const float* w, const float* scale, int scale_group_batch,
+                      int scale_stride, float* y, int64_t y_bs, void* stream);
+int locate_dwconv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* w, const float* scale,
+                        int scale_group_batch, int scale_stride, float* gx, int64_t gx_bs, void* stream);
+/* gw[row, kh, kw] = inv_scale * sum_{b,oh,ow} small[b, row or row/mult, oh, ow] big[b, row/mult or row, oh*s-ph+kh, ow*s-pw+kw]
+ * (deterministic two-stage reduction; square kernels up to 5 x 5).  w_ref / inner_partial / per-call scales as in
+ * locate_conv_wgrad; locate_dwconv_wgrad_partials(geom) doubles are written. */
+size_t locate_dwconv_wgrad_workspace_bytes(const int* geom);
+int locate_dwconv_wgrad_partials(const int* geom);
+int locate_dwconv_wgrad(const int* geom, const float* big, int64_t big_bs, const float* small, int64_t small_bs, float* gw,
+                        const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
+                        double* inner_partial, void* workspace, void* stream);
+/* Conv2d(G*cpg, G, kernel = the whole S x S map, groups = G) (libs/attention.py:15-21): y[b, g] = scale * <w[g, :], x[b, g, :]>
+ * over L = cpg*S*S contiguous elements; x [B, G*L] with batch stride x_bs, w [G, L], y / gy [B, G] dense. */
+int locate_groupdot_fwd(const float* x, int64_t x_bs, const float* w, const float* scale, int scale_group_batch,
+                        int scale_stride, float* y, int B, int G, int L, void* stream);
+int locate_groupdot_dgrad(const float* gy, const float* w, const float* scale, int scale_group_batch, int scale_stride,
+                          float* gx, int64_t gx_bs, int B, int G, int L, void* stream);
+int locate_groupdot_wgrad_partials(int G, int L);
+int locate_groupdot_wgrad(const float* x, int64_t x_bs, const float* gy, float* gw, const float* w_ref, const float* inv_scale,
+                          int scale_group_batch, int scale_stride, double* inner_partial, int B, int G, int L, void* stream);
+
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */
 int locate_nadam_chunk_elems(void);

@@ -68,6 +68,15 @@ PROTOTYPES = {
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
     "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "locate_dwconv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_i64, c_p]),
+    "locate_dwconv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_i64, c_p]),
+    "locate_dwconv_wgrad_workspace_bytes": (c_sz, [c_ip]),
+    "locate_dwconv_wgrad_partials": (c_i, [c_ip]),
+    "locate_dwconv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "locate_groupdot_fwd": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
+    "locate_groupdot_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "locate_groupdot_wgrad_partials": (c_i, [c_i, c_i]),
+    "locate_groupdot_wgrad": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
     "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),

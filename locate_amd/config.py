@@ -18,8 +18,9 @@ class NetConfig:
     bottleneck: int = 4              # BOTTLENECK            config.py:62
     min_attention_size: int = 8      # MIN_ATTENTION_SIZE    config.py:63
     attention_every_nth_layer: int = 2   # ATTENTION_EVERY_NTH_LAYER config.py:64
-    depth: int = 1                   # DEPTH                 config.py:68 (only 1 is built)
+    depth: int = 1                   # DEPTH                 config.py:68
     feature_multiplier: int = 1      # FEATURE_MULTIPLIER    config.py:55
+    separable: bool = False          # SEPARABLE             config.py:53 (depthwise k x k convs, grouped feature attention)
     glr: float = 5e-4                # GLR                   config.py:70
     dlr: float = 2e-3                # DLR                   config.py:71
     beta1: float = 0.5               # BETA_1                config.py:72
@@ -57,6 +58,4 @@ def set_default(cfg):
     global _default
     if not isinstance(cfg, NetConfig):
         raise TypeError("expected a NetConfig")
-    if cfg.depth != 1 or cfg.feature_multiplier != 1:
-        raise NotImplementedError("only DEPTH = 1 and FEATURE_MULTIPLIER = 1 (the shipped configuration) are built")
     _default = cfg

@@ -107,14 +107,23 @@ class SpectralNorm(nn.Module):
             return (x.view(b, c, 1, n), w.view(w.shape[0], w.shape[1], 1, 1), ops.ConvSpec("conv", 1, 1, 1, 0, 0),
                     lambda y: y.view(b, -1, n))
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-            if m.groups != 1 or tuple(m.dilation) != (1, 1) or m.stride[0] != m.stride[1]:
-                raise NotImplementedError("grouped / dilated / anisotropic-stride convs are not on the hot path")
+            if tuple(m.dilation) != (1, 1) or m.stride[0] != m.stride[1]:
+                raise NotImplementedError("dilated / anisotropic-stride convs are not on the hot path")
             kh, kw = m.kernel_size
             ph, pw = m.padding
             s = m.stride[0]
-            if isinstance(m, nn.ConvTranspose2d):
-                if tuple(m.output_padding) != (0, 0):
-                    raise NotImplementedError("output_padding")
+            transposed = isinstance(m, nn.ConvTranspose2d)
+            if transposed and tuple(m.output_padding) != (0, 0):
+                raise NotImplementedError("output_padding")
+            if m.groups != 1:
+                # the SEPARABLE switch (libs/conv.py:17, libs/attention.py:15-21): depthwise k x k, or one grouped conv whose
+                # kernel covers the whole map
+                if m.groups == m.in_channels:
+                    return x, w, ops.ConvSpec("convT" if transposed else "conv", kh, kw, s, ph, pw, mode="depthwise"), _identity
+                if not transposed and (kh, kw) == tuple(x.shape[2:]) and (ph, pw) == (0, 0) and m.groups == m.out_channels:
+                    return x, w, ops.ConvSpec("conv", kh, kw, 1, 0, 0, mode="groupdot"), _identity
+                raise NotImplementedError("grouped convs other than depthwise / full-size one-output-per-group are not on the hot path")
+            if transposed:
                 return x, w, ops.ConvSpec("convT", kh, kw, s, ph, pw), _identity
             b, c, h, wd = x.shape
             if s == 1 and ph == 0 and pw == 0 and kw == 1 and kh == h and kh > 1 and x.is_contiguous():
@@ -256,11 +265,17 @@ def feature_attention(in_size, features, dim=2, cfg=None):
     bfeatures = features // cfg.bottleneck
     layers = []
     input_features = features
-    for i in range(dim):
-        kernel_size = [1] * dim
-        kernel_size[i] = in_size
-        layers.extend([SpectralNorm(nn.Conv2d(input_features, bfeatures, kernel_size=kernel_size, bias=False)), NonLinear()])
-        input_features = bfeatures
+    min_features = min(input_features, bfeatures)
+    if cfg.separable and input_features % min_features == 0 and bfeatures % min_features == 0:
+        # one grouped full-size conv instead of the (S x 1), (1 x S) pair - and no RootTanh after it (attention.py:15-21)
+        layers.append(SpectralNorm(nn.Conv2d(input_features, bfeatures, kernel_size=[in_size] * dim, bias=False,
+                                             groups=min_features)))
+    else:
+        for i in range(dim):
+            kernel_size = [1] * dim
+            kernel_size[i] = in_size
+            layers.extend([SpectralNorm(nn.Conv2d(input_features, bfeatures, kernel_size=kernel_size, bias=False)), NonLinear()])
+            input_features = bfeatures
     layers.extend([SpectralNorm(nn.Conv2d(bfeatures, features, kernel_size=1, bias=False)), ChannelSoftmax(),
                    Expand(-1, features, *([in_size] * dim))])
     return nn.Sequential(*layers)
@@ -290,7 +305,7 @@ class ActivatedBaseConv(nn.Module):
         cfg = cfg or get_default()
         mid = in_features * cfg.feature_multiplier
         self.conv_0 = SpectralNorm(conv(in_channels=in_features, kernel_size=kernel, stride=stride, padding=pad, bias=False,
-                                        out_channels=mid))
+                                        out_channels=mid, groups=in_features if cfg.separable else 1))
         self.conv_1 = SpectralNorm(conv(kernel_size=1, stride=1, padding=0, out_channels=out_features, bias=False,
                                         in_channels=mid))
 
@@ -300,21 +315,48 @@ class ActivatedBaseConv(nn.Module):
 
 
 class DeepResidualConv(nn.Module):
-    """At DEPTH = 1 (the only shipped value): one ActivatedBaseConv with kernel 2*stride + (0 if transposed else 1)."""
+    """A chain of `depth` ActivatedBaseConv stages (libs/conv.py:27-72).  Stage 0 carries the stride / transposition with
+    kernel 2*stride + (0 if transposed else 1) and maps to the bottleneck width when depth > 1; the depth - 2 middle
+    stages (5x5, bottleneck -> bottleneck) and the last one (5x5, bottleneck -> out) are wrapped in Norm from the second
+    one on and in a ResModule(m=1) whenever their widths agree.  (The reference passes its conv class in the `residual`
+    slot of its helper - a truthy value - so every stage after the first is residual.)"""
     starts_with_activation = True
 
     def __init__(self, in_features, out_features, transpose, stride, use_bottleneck=True, dim=2, depth=1, cfg=None):
         super().__init__()
-        if depth > 1 or dim != 2:
-            raise NotImplementedError("DEPTH = 1, dim = 2 only (libs/config.py:68)")
+        if dim != 2:
+            raise NotImplementedError("dim = 2 only")
+        cfg = cfg or get_default()
+        min_features = min(in_features, out_features)
+        if use_bottleneck and max(in_features, out_features) // min_features < cfg.bottleneck:
+            min_features //= cfg.bottleneck
+        if depth > 1 and min_features < 1:
+            raise ValueError("DeepResidualConv(%d -> %d, depth %d): the bottleneck width is 0" % (in_features, out_features, depth))
         kernel = stride * 2 + int(not transpose)
         pad = max(kernel // 2 - stride // 2, 0) if transpose else kernel // 2
-        conv = nn.ConvTranspose2d if transpose else nn.Conv2d
-        self.conv_0 = ActivatedBaseConv(in_features, out_features, conv, kernel=kernel, stride=stride, pad=pad, cfg=cfg)
-        self.layers = [self.conv_0]
+        self.layers = []
+
+        def add_conv(cin, cout, residual, normalize, conv=nn.Conv2d, **kw):
+            layer = ActivatedBaseConv(cin, cout, conv, cfg=cfg, **kw)
+            if normalize:
+                layer = Norm(cin, layer, dim)
+            if residual and cin == cout:
+                layer = ResModule(_identity, layer, m=1)
+            setattr(self, "conv_%d" % len(self.layers), layer)
+            self.layers.append(layer)
+
+        add_conv(in_features, min_features if depth > 1 else out_features, False, False,
+                 conv=nn.ConvTranspose2d if transpose else nn.Conv2d, kernel=kernel, stride=stride, pad=pad)
+        for i in range(depth - 2):
+            add_conv(min_features, min_features, True, bool(i))
+        if depth > 1:
+            add_conv(min_features, out_features, True, bool(depth - 2))
 
     def forward(self, function_input, pre_activated=False):
-        return self.conv_0(function_input, pre_activated=pre_activated)
+        out = self.layers[0](function_input, pre_activated=pre_activated)
+        for layer in self.layers[1:]:
+            out = layer(out)
+        return out
 
 
 class LinearModule(nn.Module):

@@ -339,17 +339,33 @@ class ConvSpec:
 
     kind 'conv'  : y = R(x);            weight [M=C_out, C=C_in, KH, KW]
     kind 'convT' : y = R^T(x) (adjoint); weight [M=C_in, C=C_out, KH, KW]  (ConvTranspose2d layout)
-    """
-    __slots__ = ("kind", "kh", "kw", "stride", "pad_h", "pad_w")
 
-    def __init__(self, kind, kh, kw, stride, pad_h, pad_w):
-        self.kind, self.kh, self.kw, self.stride, self.pad_h, self.pad_w = kind, kh, kw, stride, pad_h, pad_w
+    mode 'dense' (groups = 1), 'depthwise' (groups = C_in, weight [C_in * mult, 1, KH, KW] resp. [C_in, mult, KH, KW] for
+    the transposed layer; grouped.hip) or 'groupdot' (a grouped conv whose kernel covers the whole map: per-group dot
+    products; weight [G, C_in / G, H, W])."""
+    __slots__ = ("kind", "kh", "kw", "stride", "pad_h", "pad_w", "mode")
+
+    def __init__(self, kind, kh, kw, stride, pad_h, pad_w, mode="dense"):
+        self.kind, self.kh, self.kw, self.stride, self.pad_h, self.pad_w, self.mode = kind, kh, kw, stride, pad_h, pad_w, mode
 
     def geometry(self, x_shape, w_shape):
         """Returns (geom[12] of R, output shape)."""
         B, Cx, H, W = x_shape
         M, C = w_shape[0], w_shape[1]
         s = self.stride
+        if self.mode == "groupdot":
+            if Cx % M or Cx // M != C or (H, W) != tuple(w_shape[2:]):
+                raise ValueError("grouped full-size conv: input %s does not fit weight %s" % (tuple(x_shape), tuple(w_shape)))
+            return [B, M, C * H * W] + [0] * 9, (B, M, 1, 1)
+        if self.mode == "depthwise":
+            if self.kind == "conv":
+                if C != 1 or M % Cx:
+                    raise ValueError("depthwise conv: input has %d channels, weight is %s" % (Cx, tuple(w_shape)))
+                C = Cx
+            else:
+                if Cx != M:
+                    raise ValueError("depthwise convT: input has %d channels, weight expects %d" % (Cx, M))
+                C = M * C              # R's input side = the transposed layer's output side
         if self.kind == "conv":
             if Cx != C:
                 raise ValueError("conv: input has %d channels, weight expects %d" % (Cx, C))
@@ -526,48 +542,83 @@ def _sigma_args(sigma, batch):
     return groups, batch // groups, sigma.stride(0), sigma[0, 1:]
 
 
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape):
-    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
+def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
+    """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode."""
     L = lib()
     st = _stream()
-    y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
     _, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
-    if spec.kind == "conv":
-        ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-        check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                _bs(y), _p(ws), st), "locate_conv_fwd")
+    if spec.mode == "dense":
+        if forward_of_r:
+            ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
+            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                    _bs(y), _p(ws), st), "locate_conv_fwd")
+        else:
+            ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
+            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                      _bs(y), _p(ws), st), "locate_conv_dgrad")
+        return y
+    if bias is not None:
+        raise NotImplementedError("grouped convolutions carry no bias in the reference (libs/conv.py:15, libs/attention.py:18)")
+    if spec.mode == "depthwise":
+        fn, name = (L.locate_dwconv_fwd, "locate_dwconv_fwd") if forward_of_r else (L.locate_dwconv_dgrad, "locate_dwconv_dgrad")
+        check(fn(garr, _p(x), _bs(x), _p(w), _p(inv_sigma), sbg, sst, _p(y), _bs(y), st), name)
+        return y
+    B, G, Ln = geom[:3]
+    if forward_of_r:
+        check(L.locate_groupdot_fwd(_p(x), _bs(x), _p(w), _p(inv_sigma), sbg, sst, _p(y), B, G, Ln, st), "locate_groupdot_fwd")
     else:
-        ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-        check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                  _bs(y), _p(ws), st), "locate_conv_dgrad")
+        check(L.locate_groupdot_dgrad(_p(x), _p(w), _p(inv_sigma), sbg, sst, _p(y), _bs(y), B, G, Ln, st), "locate_groupdot_dgrad")
     return y
+
+
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape):
+    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
+    y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y)
 
 
 def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma):
     """Gradient w.r.t. the layer input."""
+    if spec.mode == "groupdot":
+        gy = gy.contiguous()
+    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like))
+
+
+def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial):
+    """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>."""
     L = lib()
     st = _stream()
-    gx = torch.empty_like(x_like)
-    _, sbg, sst, inv_sigma = _sigma_args(sigma, gy.shape[0])
-    if spec.kind == "conv":
-        ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), gy.device)
-        check(L.locate_conv_dgrad(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, None, _p(gx),
-                                  _bs(gx), _p(ws), st), "locate_conv_dgrad")
+    if spec.mode == "dense":
+        ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), xin.device)
+        check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial),
+                                  _p(ws), st), "locate_conv_wgrad")
+    elif spec.mode == "depthwise":
+        ws = _ws(L.locate_dwconv_wgrad_workspace_bytes(garr), xin.device)
+        check(L.locate_dwconv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst,
+                                    _p(partial), _p(ws), st), "locate_dwconv_wgrad")
     else:
-        ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), gy.device)
-        check(L.locate_conv_fwd(garr, _p(gy), _bs(gy), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, None, _p(gx),
-                                _bs(gx), _p(ws), st), "locate_conv_fwd")
-    return gx
+        B, G, Ln = geom[:3]
+        gout = gout.contiguous()
+        check(L.locate_groupdot_wgrad(_p(xin), _bs(xin), _p(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial), B, G, Ln,
+                                      st), "locate_groupdot_wgrad")
 
 
-def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, garr, need_u, need_v):
+def _weight_grad_partials(spec, geom, garr):
+    L = lib()
+    if spec.mode == "dense":
+        return L.locate_conv_wgrad_partials(garr)
+    if spec.mode == "depthwise":
+        return L.locate_dwconv_wgrad_partials(garr)
+    return L.locate_groupdot_wgrad_partials(geom[1], geom[2])
+
+
+def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v):
     """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
     (_register_pending_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side)."""
     L = lib()
     st = _stream()
     groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
     gw = torch.empty_like(w)
-    ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), x.device)
     xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
     h = w.shape[0]
     wd = w.numel() // h
@@ -576,8 +627,7 @@ def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, garr
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
-        check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), None, _p(inv_sigma), sbg, sst, None,
-                                  _p(ws), st), "locate_conv_wgrad")
+        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None)
         dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
         gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
         Bn, Mn = gy.shape[0], gy.shape[1]
@@ -588,10 +638,9 @@ def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, garr
         return gw, gu
     # one pass: gw = G / sigma_k (G = gradient w.r.t. the normalised weight) plus the partial sums of <G, W_bar>;
     # then the rank-1 spectral-norm correction in place
-    npart = L.locate_conv_wgrad_partials(garr)
+    npart = _weight_grad_partials(spec, geom, garr)
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
-    check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w), _p(inv_sigma), 0, 0, _p(partial),
-                              _p(ws), st), "locate_conv_wgrad")
+    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial)
     dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
     check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
           "locate_sn_weight_bwd")
@@ -654,7 +703,7 @@ class SNConvFn(torch.autograd.Function):
         if need_x:
             gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma)
         if need_w or need_u or need_v:
-            gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, garr, need_u, need_v)
+            gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
             if not need_w:
                 gw = None
         if ctx.has_bias and need_b:

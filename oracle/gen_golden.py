@@ -429,11 +429,28 @@ def gen_size256():
     _gen_step_record("g13_256_narrow", 256, 2, 1)
 
 
-def _gen_step_record(name, S, B, ff):
+def gen_variants():
+    """G15-G19: the architecture switches of libs/config.py that the shipped defaults leave off:
+    DEPTH > 1 (conv.py:61-67), FEATURE_MULTIPLIER > 1 (conv.py:16,21), SEPARABLE (conv.py:17, attention.py:15-21)."""
+    which = os.environ["LOCATE_GOLDEN_VARIANT"]
+    name, S, B, ff, consts = VARIANTS[which]
+    _gen_step_record(name, S, B, ff, **consts)
+
+
+VARIANTS = {
+    "depth2": ("g15_depth2_32", 32, 4, 2, dict(DEPTH=2)),
+    "depth3_fm2": ("g16_depth3_fm2_32", 32, 4, 2, dict(DEPTH=3, FEATURE_MULTIPLIER=2)),
+    "separable": ("g17_separable_32", 32, 4, 4, dict(SEPARABLE=True)),
+    "separable_all": ("g18_separable_depth2_fm2_64", 64, 2, 2, dict(SEPARABLE=True, DEPTH=2, FEATURE_MULTIPLIER=2)),
+    "separable128": ("g19_separable_128", 128, 2, 8, dict(SEPARABLE=True)),
+}
+
+
+def _gen_step_record(name, S, B, ff, **consts):
     import warnings
     import torch
     from ref_loader import load_reference
-    ns = load_reference(S, ff)
+    ns = load_reference(S, ff, **consts)
     warnings.simplefilter("ignore")
     G, GO, D, DO = _build_models(ns, 999)
     latent = torch.randn(B, S)
@@ -455,7 +472,7 @@ def _gen_step_record(name, S, B, ff):
 
 
 GROUPS = {"ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
-          "config2": gen_config2, "size256": gen_size256}
+          "config2": gen_config2, "size256": gen_size256, "variants": gen_variants}
 
 
 def main(argv):
@@ -465,6 +482,7 @@ def main(argv):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {})]
     runs += [("init", {"LOCATE_GOLDEN_INIT_CFG": c}) for c in ("tiny32", "full32", "full64")]
+    runs += [("variants", {"LOCATE_GOLDEN_VARIANT": v}) for v in VARIANTS]
     for name, extra in runs:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), name], env=dict(env, **extra),
                               cwd="/tmp")

@@ -34,6 +34,9 @@ class NetConfig:
     bottleneck: int = 4            # config.py:62
     min_attention_size: int = 8    # config.py:63
     attention_every: int = 2       # config.py:64
+    depth: int = 1                 # config.py:68  DEPTH
+    feature_multiplier: int = 1    # config.py:55  FEATURE_MULTIPLIER
+    separable: bool = False        # config.py:53  SEPARABLE
     glr: float = 5e-4              # config.py:70
     dlr: float = 2e-3              # config.py:71
     beta1: float = 0.5             # config.py:72
@@ -195,25 +198,48 @@ def sn_weight(P, prefix):
 # ------------------------------------------------------------------------------------------------
 # layers, addressed by state_dict prefix
 # ------------------------------------------------------------------------------------------------
-def activated_base_conv(P, prefix, x, kernel, stride, pad, transposed):
+def activated_base_conv(P, prefix, x, kernel, stride, pad, transposed, separable=False):
     """conv.py:11-24: SN 1x1 ( RootTanh ( SN kxk ( RootTanh x ) ) ), no biases; both convs transposed when
-    `transposed` (conv.py:49-52) so weights are [C_in, C_out, k, k]."""
+    `transposed` (conv.py:49-52) so weights are [C_in, C_out, k, k].  SEPARABLE: the k x k conv is depthwise
+    (groups = C_in, conv.py:17) - the channel multiplier is read off the weight."""
     w0 = sn_weight(P, prefix + "conv_0.module.")
+    groups = x.shape[1] if separable else 1
     h = root_tanh(x)
     if transposed:
-        h = F.conv_transpose2d(h, w0, None, stride, pad)
+        h = F.conv_transpose2d(h, w0, None, stride, pad, groups=groups)
     else:
-        h = F.conv2d(h, w0, None, stride, pad)
+        h = F.conv2d(h, w0, None, stride, pad, groups=groups)
     w1 = sn_weight(P, prefix + "conv_1.module.")
     h = root_tanh(h)
     return F.conv_transpose2d(h, w1) if transposed else F.conv2d(h, w1)
 
 
-def deep_residual_conv(P, prefix, x, transposed, stride):
-    """conv.py:27-72 at DEPTH=1: kernel = 2*stride + (0 if transposed else 1) (conv.py:36); pads utils.py:34-39."""
+def deep_residual_conv(P, prefix, x, transposed, stride, cfg=None, cin=None, cout=None, use_bottleneck=True, depth=1):
+    """conv.py:27-72.  Stage 0: kernel = 2*stride + (0 if transposed else 1) (conv.py:36), pads utils.py:34-39, to the
+    bottleneck width when depth > 1 (conv.py:31-34,61-62).  Stages 1 .. depth-1 (conv.py:63-67): 5x5 stride-1 regular
+    convs; `residual` receives the conv class (truthy), so each is a ResModule(m=1) when its widths agree (conv.py:55-56),
+    around a Norm from the second of them on (`normalize=bool(i)` / `bool(depth - 2)`)."""
+    sep = bool(cfg.separable) if cfg is not None else False
     kernel = stride * 2 + int(not transposed)
     pad = max(kernel // 2 - stride // 2, 0) if transposed else kernel // 2
-    return activated_base_conv(P, prefix + "conv_0.", x, kernel, stride, pad, transposed)
+    x = activated_base_conv(P, prefix + "conv_0.", x, kernel, stride, pad, transposed, sep)
+    if depth <= 1:
+        return x
+    mid = min(cin, cout)
+    if use_bottleneck and max(cin, cout) // mid < cfg.bottleneck:
+        mid //= cfg.bottleneck
+    stages = [(mid, mid, bool(i)) for i in range(depth - 2)] + [(mid, cout, bool(depth - 2))]
+    for k, (a, b, normalize) in enumerate(stages, start=1):
+        p = prefix + "conv_%d." % k
+        residual = a == b
+        q = p + "layer_module." if residual else p
+        h = x
+        if normalize:
+            h = inplace_norm(h, P[q + "i_norm.weight"], P[q + "i_norm.bias"])
+            q += "module."
+        h = activated_base_conv(P, q, h, 5, 1, 2, False, sep)
+        x = residual_gate(x, h, P[p + "gamma"]) if residual else h
+    return x
 
 
 def feature_pooling(x, out_features):
@@ -244,14 +270,20 @@ def scale_layer(P, prefix, x, cin, cout, stride, transposed):
     return x
 
 
-def feature_attention(P, prefix, x, features, size, bottleneck):
-    """attention.py:9-37 (SEPARABLE=False): conv (S x 1) -> RootTanh -> conv (1 x S) -> RootTanh -> conv 1x1 ->
-    softmax over channels -> expand to [B, C, S, S] (util_modules.py:6-12)."""
-    h = F.conv2d(x, sn_weight(P, prefix + "0.module."))
-    h = root_tanh(h)
-    h = F.conv2d(h, sn_weight(P, prefix + "2.module."))
-    h = root_tanh(h)
-    h = F.conv2d(h, sn_weight(P, prefix + "4.module."))
+def feature_attention(P, prefix, x, features, size, bottleneck, separable=False):
+    """attention.py:9-37: conv (S x 1) -> RootTanh -> conv (1 x S) -> RootTanh -> conv 1x1 -> softmax over channels ->
+    expand to [B, C, S, S] (util_modules.py:6-12).  SEPARABLE (attention.py:15-21): ONE full-size (S x S) conv with
+    groups = C // BOTTLENECK takes the place of the pair - and no RootTanh separates it from the 1x1 conv."""
+    bf = features // bottleneck
+    if separable and features % min(features, bf) == 0:
+        h = F.conv2d(x, sn_weight(P, prefix + "0.module."), groups=bf)
+        h = F.conv2d(h, sn_weight(P, prefix + "1.module."))
+    else:
+        h = F.conv2d(x, sn_weight(P, prefix + "0.module."))
+        h = root_tanh(h)
+        h = F.conv2d(h, sn_weight(P, prefix + "2.module."))
+        h = root_tanh(h)
+        h = F.conv2d(h, sn_weight(P, prefix + "4.module."))
     h = torch.softmax(h, dim=1)
     return h.view(h.size(0), -1, 1, 1).expand(-1, features, size, size)
 
@@ -277,12 +309,12 @@ def block_forward(P, prefix, x, cin, cout, size, idx, transposed, cfg, scales=No
     scaled = scale_layer(P, prefix + "scale_layer.", x, cin, cout, 2, transposed)
     p = prefix + "res_module_i."
     h = inplace_norm(x, _norm_scale(P, p + "layer_module.", scales[0]), P[p + "layer_module.i_norm.bias"])
-    h = deep_residual_conv(P, p + "layer_module.module.", h, transposed, 2)
+    h = deep_residual_conv(P, p + "layer_module.module.", h, transposed, 2, cfg, cin, cout, True, cfg.depth)
     out = residual_gate(scaled, h, P[p + "gamma"])
     if cfg.has_attention(size, idx):
         p = prefix + "res_module_f."
         h = inplace_norm(out, _norm_scale(P, p + "layer_module.", scales[1]), P[p + "layer_module.i_norm.bias"])
-        h = feature_attention(P, p + "layer_module.module.", h, cout, size, cfg.bottleneck)
+        h = feature_attention(P, p + "layer_module.module.", h, cout, size, cfg.bottleneck, cfg.separable)
         out = residual_gate(out, h, P[p + "gamma"])
         p = prefix + "res_module_s."
         h = inplace_norm(out, _norm_scale(P, p + "layer_module.", scales[2]), P[p + "layer_module.i_norm.bias"])
@@ -312,7 +344,7 @@ def generator_forward(P, noise, latent, cfg):
             mul_idx += 1
             operand.append(pre.view(*pre.shape, 1, 1))
         x = block_forward(P, "conv_block.block_%d." % i, x, feats[i], feats[i + 1], sizes[i], i, True, cfg, operand)
-    x = deep_residual_conv(P, "out_conv.", x, False, 1)
+    x = deep_residual_conv(P, "out_conv.", x, False, 1, cfg)
     return torch.tanh(x)
 
 
@@ -320,11 +352,11 @@ def discriminator_forward(P, x, cfg):
     """models.py:96-97: stem ResModule(Scale(3->w0), DRC(3->w0, 5x5 s2)) -> blocks -> 3x3 + 1x1 head."""
     feats, sizes = cfg.d_features(), cfg.d_block_sizes()
     scaled = scale_layer(P, "main.0.residual_module.", x, 3, feats[0], 2, False)
-    h = deep_residual_conv(P, "main.0.layer_module.", x, False, 2)
+    h = deep_residual_conv(P, "main.0.layer_module.", x, False, 2, cfg)
     x = residual_gate(scaled, h, P["main.0.gamma"])
     for i in range(cfg.n_blocks):
         x = block_forward(P, "main.1.block_%d." % i, x, feats[i], feats[i + 1], sizes[i], i, False, cfg)
-    return deep_residual_conv(P, "main.2.", x, False, 1)
+    return deep_residual_conv(P, "main.2.", x, False, 1, cfg)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -28,8 +28,9 @@ def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "libs"))
 
 
-def load_reference(image_size=128, base_feature_factor=8, quiet=True):
-    """Import the reference's `libs.*` modules for one configuration; returns a namespace."""
+def load_reference(image_size=128, base_feature_factor=8, quiet=True, **constants):
+    """Import the reference's `libs.*` modules for one configuration; returns a namespace.  `constants` overrides further
+    libs/config.py switches by name (DEPTH, FEATURE_MULTIPLIER, SEPARABLE) before the modules that bind them are imported."""
     if "libs" in sys.modules:
         raise RuntimeError("reference already imported in this process (one process = one config)")
     sys.dont_write_bytecode = True
@@ -60,6 +61,10 @@ def load_reference(image_size=128, base_feature_factor=8, quiet=True):
         cfg.GEN_FEATURES = cfg.FACTOR ** int(math.log(cfg.IMAGE_SIZE, cfg.G_STRIDE)) * cfg.BASE_FEATURE_FACTOR * 3
         cfg.DIS_FEATURES = cfg.FACTOR ** int(math.log(cfg.IMAGE_SIZE, cfg.D_STRIDE)) * cfg.BASE_FEATURE_FACTOR
         cfg.INPUT_VECTOR_Z = cfg.IMAGE_SIZE
+        for key, value in constants.items():
+            if not hasattr(cfg, key):
+                raise KeyError("libs/config.py has no constant %r" % key)
+            setattr(cfg, key, value)
         ns = types.SimpleNamespace(config=cfg)
         for mod in ("activation", "inplace_norm", "merge", "spectral_norm", "conv", "attention", "scale",
                     "linear", "util_modules", "block", "models", "utils", "nadam", "grad_penalty"):

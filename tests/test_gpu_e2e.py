@@ -106,19 +106,27 @@ def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d):
     assert_close(img.cpu(), z["sample/image"], 1e-3)
 
 
-@pytest.mark.parametrize("name,S,B,ff,stacked", [
-    ("g11_config1", 32, 8, 8, False),         # BASELINE configs[0]: 32x32, batch 8, full width
-    ("g11_config1", 32, 8, 8, True),
-    ("g14_config2_64", 64, 64, 8, True),      # configs[1]: the benchmark workload itself, from the reference
-    ("g12_config3_128", 128, 2, 8, True),     # configs[3]: the reference's default 128x128 architecture (C up to 1536)
-    ("g13_256_narrow", 256, 2, 1, True),      # configs[4]'s 256x256 architecture at 1/8 width (attention over N = 65 536)
+@pytest.mark.parametrize("name,S,B,ff,stacked,switches", [
+    ("g11_config1", 32, 8, 8, False, {}),         # BASELINE configs[0]: 32x32, batch 8, full width
+    ("g11_config1", 32, 8, 8, True, {}),
+    ("g14_config2_64", 64, 64, 8, True, {}),      # configs[1]: the benchmark workload itself, from the reference
+    ("g12_config3_128", 128, 2, 8, True, {}),     # configs[3]: the reference's default 128x128 architecture (C up to 1536)
+    ("g13_256_narrow", 256, 2, 1, True, {}),      # configs[4]'s 256x256 architecture at 1/8 width (attention over N = 65 536)
+    # the libs/config.py switches the shipped defaults leave off
+    ("g15_depth2_32", 32, 4, 2, True, dict(depth=2)),
+    ("g16_depth3_fm2_32", 32, 4, 2, False, dict(depth=3, feature_multiplier=2)),
+    ("g16_depth3_fm2_32", 32, 4, 2, True, dict(depth=3, feature_multiplier=2)),
+    ("g17_separable_32", 32, 4, 4, False, dict(separable=True)),
+    ("g17_separable_32", 32, 4, 4, True, dict(separable=True)),
+    ("g18_separable_depth2_fm2_64", 64, 2, 2, True, dict(separable=True, depth=2, feature_multiplier=2)),
+    ("g19_separable_128", 128, 2, 8, True, dict(separable=True)),   # configs[3] read as depthwise-factorised blocks
 ])
-def test_full_architectures_step_vs_reference_record(name, S, B, ff, stacked):
+def test_full_architectures_step_vs_reference_record(name, S, B, ff, stacked, switches):
     """Seeded construction + one step of the full architectures; losses, output and per-tensor gradient / post-step
     norms against what the reference produced (oracle/gen_golden.py: g11 - g14)."""
     from locate_amd import Discriminator, Generator, NetConfig, TrainStep, get_model
     z = load_golden(name)
-    cfg = NetConfig(image_size=S, base_feature_factor=ff)
+    cfg = NetConfig(image_size=S, base_feature_factor=ff, **switches)
     torch.manual_seed(cfg.seed)
     dev = torch.device("cuda:0")
     G, GO = get_model(Generator(cfg), cfg.glr, dev)

@@ -228,11 +228,12 @@ def test_batched_spectral_norm_equals_per_layer():
             assert_close(b.grad.cpu(), a.grad.cpu(), 1e-5, k)
 
 
-@pytest.mark.parametrize("size,ff,B", [(32, 1, 4), (32, 4, 2), (64, 1, 2)])
-def test_stacked_discriminator_pass_equals_three_calls(size, ff, B):
+@pytest.mark.parametrize("size,ff,B,switches", [(32, 1, 4, {}), (32, 4, 2, {}), (64, 1, 2, {}),
+                                                (32, 4, 2, dict(separable=True, depth=2, feature_multiplier=2))])
+def test_stacked_discriminator_pass_equals_three_calls(size, ff, B, switches):
     """D over a [3B] batch with stacked=3 == three D calls in order (outputs, u/v state, all gradients incl. u/v)."""
     from locate_amd import Discriminator, NetConfig
-    cfg = NetConfig(image_size=size, base_feature_factor=ff)
+    cfg = NetConfig(image_size=size, base_feature_factor=ff, **switches)
     torch.manual_seed(11)
     D1 = Discriminator(cfg).to(dev())
     D2 = Discriminator(cfg).to(dev())
@@ -305,6 +306,96 @@ def test_conv_igemm_vs_cpu(kind, cin, cout, k, s, p, B, H, W):
     assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
     assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
     assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
+
+
+GROUPED_CASES = [
+    # kind, Cin, mult, k, stride, pad, B, H, W        (groups = Cin: the SEPARABLE switch, libs/conv.py:17)
+    ("conv", 3, 1, 5, 2, 2, 4, 16, 16),        # D stem conv_0
+    ("conv", 32, 1, 5, 2, 2, 3, 12, 12),
+    ("conv", 20, 2, 5, 2, 2, 2, 9, 7),         # FEATURE_MULTIPLIER = 2, odd sizes
+    ("conv", 48, 1, 3, 1, 1, 2, 10, 10),       # G head conv_0
+    ("conv", 12, 3, 5, 1, 2, 2, 8, 8),         # DEPTH > 1 middle stage, multiplier 3
+    ("conv", 96, 1, 5, 2, 2, 40, 32, 32),      # many chunks in the weight-gradient reduction
+    ("convT", 64, 1, 4, 2, 1, 3, 2, 2),        # G block 0
+    ("convT", 24, 2, 4, 2, 1, 2, 8, 8),        # transposed with multiplier (weights [C_in, 2, 4, 4])
+    ("convT", 10, 1, 4, 2, 1, 1, 5, 3),        # odd sizes
+    ("full", 32, 8, 8, 1, 0, 5, 8, 8),         # feature attention: Conv2d(32 -> 8, kernel 8x8, groups = 8)
+    ("full", 12, 3, 16, 1, 0, 3, 16, 16),      # 4 channels per group, L = 1024
+    ("full", 6, 3, 5, 1, 0, 2, 5, 5),          # L = 50: not a multiple of 4
+]
+
+
+def _grouped_layer(kind, cin, mult, k, s, p):
+    nn = torch.nn
+    if kind == "conv":
+        return nn.Conv2d(cin, cin * mult, k, stride=s, padding=p, bias=False, groups=cin), cin
+    if kind == "convT":
+        return nn.ConvTranspose2d(cin, cin * mult, k, stride=s, padding=p, bias=False, groups=cin), cin
+    return nn.Conv2d(cin, mult, k, bias=False, groups=mult), mult        # "full": mult = number of groups = outputs
+
+
+def _grouped_apply(kind, x, w, s, p, groups):
+    if kind == "convT":
+        return F.conv_transpose2d(x, w, None, s, p, groups=groups)
+    return F.conv2d(x, w, None, s, p, groups=groups)
+
+
+@pytest.mark.parametrize("kind,cin,mult,k,s,p,B,H,W", GROUPED_CASES)
+def test_grouped_convs_vs_cpu(kind, cin, mult, k, s, p, B, H, W):
+    """Depthwise (regular / transposed, with channel multiplier) and full-size grouped convs: forward, data gradient,
+    weight gradient and the spectral-norm state / u, v gradients against ATen CPU grouped convs through the oracle's
+    spectral norm."""
+    from locate_amd import SpectralNorm
+    from oracle import locate_oracle as O
+    torch.manual_seed(cin * 100 + mult + k)
+    inner, groups = _grouped_layer(kind, cin, mult, k, s, p)
+    mod = SpectralNorm(inner)
+    sd = {kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(B, cin, H, W)
+    P = O.make_params(sd, trainable_uv=True)
+    xr = x.clone().requires_grad_(True)
+    yr = _grouped_apply(kind, xr, O.sn_weight(P, "module."), s, p, groups)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    mod = mod.to(dev())
+    mod.requires_grad_(True)
+    xg = x.to(dev()).requires_grad_(True)
+    yg = mod(xg)
+    yg.backward(g.to(dev()))
+    assert_close(yg.cpu(), yr, 2e-5, "y")
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
+    assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
+    assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
+    assert_close(mod.module.weight_u.grad.cpu(), P["module.weight_u"].grad, 5e-4, "du")
+    assert_close(mod.module.weight_v.grad.cpu(), P["module.weight_v"].grad, 5e-4, "dv")
+
+
+@pytest.mark.parametrize("kind,cin,mult,k,s,p,B,H,W", [GROUPED_CASES[2], GROUPED_CASES[7], GROUPED_CASES[10]])
+def test_grouped_convs_stacked_calls(kind, cin, mult, k, s, p, B, H, W):
+    """One pass over three stacked calls (own sigma per call) == the three calls in order, for the grouped kernels."""
+    from locate_amd import SpectralNorm, ops
+    torch.manual_seed(5)
+    inner, _ = _grouped_layer(kind, cin, mult, k, s, p)
+    m1 = SpectralNorm(inner).to(dev())
+    import copy
+    m2 = copy.deepcopy(m1)
+    m1.requires_grad_(True)
+    m2.requires_grad_(True)
+    xs = [torch.randn(B, cin, H, W, device=dev()) for _ in range(3)]
+    ys = [m1(x) for x in xs]
+    gs = [torch.randn_like(y) for y in ys]
+    torch.autograd.backward(ys, gs)
+    mm = m2.module
+    runs = [ops.sn_power_iteration(mm.weight_bar, mm.weight_u, mm.weight_v) for _ in range(3)]
+    m2._pre = (torch.stack([r[0] for r in runs]), torch.stack([r[1] for r in runs]))
+    with ops.stacked_calls(3):
+        y_all = m2(torch.cat(xs))
+    y_all.backward(torch.cat(gs))
+    assert_close(y_all.detach().cpu(), torch.cat(ys).detach().cpu(), 1e-5, "y")
+    for name in ("weight_bar", "weight_u", "weight_v"):
+        a, b = getattr(m1.module, name), getattr(m2.module, name)
+        assert_close(b.detach().cpu(), a.detach().cpu(), 1e-6, name)
+        assert_close(b.grad.cpu(), a.grad.cpu(), 1e-3 if name != "weight_bar" else 1e-4, "grad " + name)
 
 
 def test_conv_on_channel_slice_view():

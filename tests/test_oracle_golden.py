@@ -245,14 +245,22 @@ def test_config_feature_lists():
     assert c.d_features() == [32, 64, 128, 256, 512, 1024, 2048, 2048]
 
 
-@pytest.mark.parametrize("name,S,B,ff", [("g11_config1", 32, 8, 8), ("g13_256_narrow", 256, 2, 1)])
-def test_oracle_full_architectures_vs_reference_record(name, S, B, ff):
+VARIANT_RECORDS = [          # the libs/config.py switches the shipped defaults leave off (oracle/gen_golden.py VARIANTS)
+    ("g15_depth2_32", 32, 4, 2, dict(depth=2)),
+    ("g16_depth3_fm2_32", 32, 4, 2, dict(depth=3, feature_multiplier=2)),
+    ("g17_separable_32", 32, 4, 4, dict(separable=True)),
+    ("g18_separable_depth2_fm2_64", 64, 2, 2, dict(separable=True, depth=2, feature_multiplier=2)),
+]
+
+
+@pytest.mark.parametrize("name,S,B,ff,switches", [("g11_config1", 32, 8, 8, {}), ("g13_256_narrow", 256, 2, 1, {})] + VARIANT_RECORDS)
+def test_oracle_full_architectures_vs_reference_record(name, S, B, ff, switches):
     """The CPU oracle on the full architectures (seeded construction through the host mirror, which reproduces the
     reference's RNG draw order): losses, output and per-tensor gradient norms of one step as recorded from the
-    reference (oracle/gen_golden.py g11 / g13)."""
+    reference (oracle/gen_golden.py g11 / g13, and g15 - g18 for DEPTH / FEATURE_MULTIPLIER / SEPARABLE)."""
     from locate_amd import Discriminator, Generator, NetConfig, init
     z = load_golden(name)
-    cfg = NetConfig(image_size=S, base_feature_factor=ff)
+    cfg = NetConfig(image_size=S, base_feature_factor=ff, **switches)
     torch.manual_seed(cfg.seed)
     G = Generator(cfg)
     G.apply(init)
@@ -262,7 +270,7 @@ def test_oracle_full_architectures_vs_reference_record(name, S, B, ff):
     real = torch.randn(B, 3, S, S).clamp(-1, 1)
     aug = torch.randn(B, 3, S, S).clamp(-1, 1)
     np.testing.assert_array_equal(latent[0, :4].numpy(), z["after_build_rng_check"])
-    ocfg = O.NetConfig(image_size=S, base_feature_factor=ff)
+    ocfg = O.NetConfig(image_size=S, base_feature_factor=ff, **switches)
     PG = O.make_params({k: v.clone() for k, v in G.state_dict().items()})
     PD = O.make_params({k: v.clone() for k, v in D.state_dict().items()})
     og, od = O.Nadam(ocfg.glr, (ocfg.beta1, ocfg.beta2)), O.Nadam(ocfg.dlr, (ocfg.beta1, ocfg.beta2))
