@@ -717,16 +717,20 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         Bs[buf][2][kgrp][ncol] = *reinterpret_cast<uint4*>(&l);
     };
 
+    // Software pipeline: while the matrix pipe works through the first half of a stage's MFMAs, the wave converts and
+    // writes the NEXT tile (its global loads were issued half a stage earlier) and immediately re-issues the loads for the
+    // tile after that into the registers it just freed; the second half of the MFMAs follows.  Global-load latency and
+    // the fp32 -> 3 x bf16 split are then in the shadow of the wave's own MFMAs, with no additional registers.
     if (nsteps > 0) {
-        issue_loads();
+        issue_loads();                       // tile 0
         store_tiles(0);
+        issue_loads();                       // tile 1 (past the end: inside the panel's zero tail, IG_TAIL rows)
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
+    constexpr int NMF = TM * TN * 6, HALF = NMF / 2;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        issue_loads();                       // prefetch of step s + 1 (redundant but in bounds on the last iteration)
-        __builtin_amdgcn_sched_barrier(0);
         bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -736,19 +740,27 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][lrow][(wn * TN + j) * 32 + lcol]);
+        auto mfmas = [&](int lo, int hi) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
-            }
+                for (int j = 0; j < TN; ++j) {
+                    const int base = (i * TN + j) * 6;
+                    if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                    if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
+                    if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
+                    if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                    if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
+                    if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                }
+        };
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
+        mfmas(0, HALF);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);                // tile s + 1
+        issue_loads();                       // tile s + 2
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(HALF, NMF);
         __syncthreads();
     }
     // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
@@ -1538,15 +1550,17 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     const int nsteps = (n_end - n_begin + WB_BK - 1) / WB_BK;
     const int lrow = lane >> 5, lcol = lane & 31;
     const int rhalf = lrow ^ ((lcol >> 3) & 1);          // fragment rows are tile_row0 + lcol with tile_row0 % 32 == 0
+    // same software pipeline as conv_igemm_bx6_kernel: the next tile is split and written, and the loads of the one after
+    // it re-issued, between the two halves of a stage's MFMAs
     if (nsteps > 0) {
         load_tiles(n_begin);
         store_tiles(0);
+        load_tiles(n_begin + WB_BK);                 // beyond n_end: every lane masked, nothing is read
     }
     __syncthreads();
+    constexpr int NMF = TM * TN * 6, HALF = NMF / 2;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        load_tiles(n_begin + (s + 1) * WB_BK);       // beyond n_end: every lane masked, nothing is read
-        __builtin_amdgcn_sched_barrier(0);
         bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1556,19 +1570,27 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+        auto mfmas = [&](int lo, int hi) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
-            }
+                for (int j = 0; j < TN; ++j) {
+                    const int base = (i * TN + j) * 6;
+                    if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                    if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
+                    if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
+                    if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                    if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
+                    if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                }
+        };
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
+        mfmas(0, HALF);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);                               // tile s + 1
+        load_tiles(n_begin + (s + 2) * WB_BK);              // tile s + 2
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(HALF, NMF);
         __syncthreads();
     }
     wgrad_epilogue<WGM, WGN, TM, TN>(p, acc, r0, m0, wm, wn, lane, wid, tid);
