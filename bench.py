@@ -35,6 +35,7 @@ def parse():
                     help="run the three discriminator passes of the D-step on three streams (measured: no gain under "
                          "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--wgrad-overlap", action="store_true", help="weight gradients on a second stream beside the backward pass")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the G-step's generator pass in line instead of on a second stream beside the D-step")
     return ap.parse_args()
@@ -152,7 +153,8 @@ def main():
         broadcast_module_state(D, 0)
         late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
         red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters(), late=late_v)
-    step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d)
+    step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
+                     overlap_wgrad=args.wgrad_overlap)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)

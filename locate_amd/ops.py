@@ -420,8 +420,57 @@ def _panel(owner, w, geom, garr, adjoint):
 # ------------------------------------------------------------------------------------------------
 class _PendingDV:
     layers = {}          # id(v) -> (v, u, w, h, wd, state)
-    scheduled = False
     tables = {}          # tuple(ids) -> (device table, max_h, max_wd, keep-alive)
+
+
+class weight_grad_stream:
+    """Context for backward(): weight gradients of the spectral-normalised contractions (and their spectral-norm
+    backward) are launched on `stream` instead of the stream of the backward pass.  They sit beside the pass's critical
+    path - the chain of input gradients - and most kernels of that chain are too small to fill the chip, so the two run
+    concurrently.  The results are NOT returned through autograd (a consumer on the main stream could read them too
+    early): they are assigned to / accumulated into `.grad` of the weight, u and v parameters by a callback at the end of
+    the backward pass, after the main stream has joined the side stream.  Consequences: only for `.backward()`
+    (torch.autograd.grad would see no weight gradients), and tensor hooks on those parameters do not fire."""
+    current = None
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = weight_grad_stream.current
+        weight_grad_stream.current = self.stream
+
+    def __exit__(self, *exc):
+        weight_grad_stream.current = self.prev
+        return False
+
+
+class _BackwardEnd:
+    scheduled = False
+    side = None          # side stream with work of this backward pass on it
+    pending = []         # (parameter, gradient tensor produced on the side stream)
+    keep = []            # operands of the side-stream kernels: alive until the join, so their memory is not recycled under them
+
+
+def _schedule_backward_end():
+    if not _BackwardEnd.scheduled:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _BackwardEnd.scheduled = True
+
+
+def _end_of_backward():
+    _BackwardEnd.scheduled = False
+    side, _BackwardEnd.side = _BackwardEnd.side, None
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        pending, _BackwardEnd.pending = _BackwardEnd.pending, []
+        _BackwardEnd.keep = []
+        for param, grad in pending:
+            if param.grad is None:
+                param.grad = grad
+            else:
+                param.grad.add_(grad)
+    _finalize_pending_dv()
 
 
 def _register_pending_dv(v_param, u_param, w, h, wd):
@@ -436,9 +485,7 @@ def _register_pending_dv(v_param, u_param, w, h, wd):
         raise RuntimeError("a spectral-norm layer was differentiated through more than 4 forwards in one backward pass")
     st["k"] = k + 1
     _PendingDV.layers[id(v_param)] = (v_param, u_param, w, h, wd, st)
-    if not _PendingDV.scheduled:
-        torch.autograd.Variable._execution_engine.queue_callback(_finalize_pending_dv)
-        _PendingDV.scheduled = True
+    _schedule_backward_end()
     return st["dsig"][k:]
 
 
@@ -446,7 +493,6 @@ def _finalize_pending_dv():
     import struct
     layers = list(_PendingDV.layers.values())
     _PendingDV.layers = {}
-    _PendingDV.scheduled = False
     if not layers:
         return
     key = tuple((id(v), w.data_ptr(), u.data_ptr()) for v, u, w, _, _, _ in layers)
@@ -703,9 +749,22 @@ class SNConvFn(torch.autograd.Function):
         if need_x:
             gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma)
         if need_w or need_u or need_v:
-            gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
-            if not need_w:
-                gw = None
+            side = weight_grad_stream.current
+            if side is None:
+                gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                if not need_w:
+                    gw = None
+            else:
+                side.wait_stream(torch.cuda.current_stream())        # gy (and x) are complete on the pass's stream
+                with torch.cuda.stream(side):
+                    sgw, sgu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                _BackwardEnd.side = side
+                _BackwardEnd.keep.append((x, gy, y, bsaved, w, sigma, wv))
+                if need_w:
+                    _BackwardEnd.pending.append((ctx.owner, sgw.view(ctx.owner.shape)))
+                if need_u:
+                    _BackwardEnd.pending.append((ctx.u, sgu))
+                _schedule_backward_end()
         if ctx.has_bias and need_b:
             gb = _bias_grad(gy)
         # gv is assigned to v.grad by _finalize_pending_dv at the end of this backward pass

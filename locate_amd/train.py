@@ -44,8 +44,14 @@ def g_loss(d_fake):
 
 class TrainStep:
     def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None,
-                 concurrent_d=False, stacked_d=None):
+                 concurrent_d=False, stacked_d=None, overlap_wgrad=False):
         self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
+        # overlap_wgrad: the weight gradients of a backward pass run on a second stream beside its chain of input gradients
+        # (ops.weight_grad_stream); same values, the parameters' .grad are complete when backward() returns.  Off by
+        # default: measured neutral under hipGraph replay (12.76 vs 12.74 ms at config 2 - the fork/join branches of one
+        # captured graph do not run side by side) and slower eagerly (more host work per layer)
+        self.overlap_wgrad = bool(overlap_wgrad)
+        self._wgrad_side = None
         # stacked_d: the D-step's three discriminator passes (real / fake / augmented) run as ONE pass over a [3B] batch
         # with per-call InPlaceNorm statistics and per-call spectral-norm sigma (three power iterations up front, in the
         # reference's order) - same values, a third of the launches, no cross-graph gradient accumulation.
@@ -61,6 +67,15 @@ class TrainStep:
         # iterations of the three forwards are done first, in the reference's order real / fake / augmented).
         self.concurrent_d = concurrent_d
         self._streams = None
+
+    def _backward(self, outputs, grads):
+        from . import ops
+        if not self.overlap_wgrad:
+            return torch.autograd.backward(outputs, grads)
+        if self._wgrad_side is None:
+            self._wgrad_side = torch.cuda.Stream()
+        with ops.weight_grad_stream(self._wgrad_side):
+            return torch.autograd.backward(outputs, grads)
 
     # ---- the four phases of one iteration (kept separate so that each can be its own hipGraph) --------------
     def _d_forwards_concurrent(self, latent, real, aug):
@@ -110,7 +125,7 @@ class TrainStep:
             losses, g_t, _, _ = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
             if self.reducer_d is not None:
                 self.reducer_d.begin()
-            d_all.backward(g_t._base.view_as(d_all))                           # :156
+            self._backward([d_all], [g_t._base.view_as(d_all)])                 # :156
             if self.reducer_d is not None:
                 self.reducer_d.finish()
             return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
@@ -126,7 +141,7 @@ class TrainStep:
         losses, g_t, g_f, g_a = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
         if self.reducer_d is not None:
             self.reducer_d.begin()
-        torch.autograd.backward([d_true, d_fake, d_aug], [g_t.view_as(d_true), g_f.view_as(d_fake), g_a.view_as(d_aug)])  # :156
+        self._backward([d_true, d_fake, d_aug], [g_t.view_as(d_true), g_f.view_as(d_fake), g_a.view_as(d_aug)])  # :156
         if self.reducer_d is not None:
             self.reducer_d.finish()
         return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
@@ -152,7 +167,7 @@ class TrainStep:
                 loss, g = g_loss(d_out)
                 if self.reducer_g is not None:
                     self.reducer_g.begin()
-                d_out.backward(g.view_as(d_out))
+                self._backward([d_out], [g.view_as(d_out)])
                 if self.reducer_g is not None:
                     self.reducer_g.finish()
         finally:
@@ -173,7 +188,7 @@ class TrainStep:
             loss, g = g_loss(d_out)
             if self.reducer_g is not None:
                 self.reducer_g.begin()
-            d_out.backward(g.view_as(d_out))       # :169
+            self._backward([d_out], [g.view_as(d_out)])   # :169
             if self.reducer_g is not None:
                 self.reducer_g.finish()
         finally:

@@ -33,7 +33,7 @@ def assert_step_close(got, want, lr, step, what):
     assert float(d.max()) <= 2.5 * lr, "%s: max |delta| = %.3e lr" % (what, float(d.max()) / lr)
 
 
-def _build_tiny(z, batched_sn=False, concurrent_d=False, stacked_d=False):
+def _build_tiny(z, batched_sn=False, concurrent_d=False, stacked_d=False, overlap_wgrad=False):
     from locate_amd import Discriminator, Generator, Nadam, NetConfig, TrainStep
     cfg = NetConfig(image_size=32, base_feature_factor=1)
     G, D = Generator(cfg), Discriminator(cfg)
@@ -45,17 +45,20 @@ def _build_tiny(z, batched_sn=False, concurrent_d=False, stacked_d=False):
     G.batched_spectral_norm = D.batched_spectral_norm = batched_sn
     step = TrainStep(G, D, Nadam(G.parameters(), lr=cfg.glr, betas=(cfg.beta1, cfg.beta2)),
                      Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), concurrent_d=concurrent_d,
-                     stacked_d=stacked_d)
+                     stacked_d=stacked_d, overlap_wgrad=overlap_wgrad)
     return cfg, G, D, step, dev
 
 
-@pytest.mark.parametrize("batched_sn,concurrent_d,stacked_d", [(False, False, False), (True, False, False), (True, True, False),
-                                                                (True, False, True)])
-def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d):
+@pytest.mark.parametrize("batched_sn,concurrent_d,stacked_d,overlap_wgrad", [
+    (False, False, False, False), (True, False, False, False), (True, True, False, False), (True, False, True, False),
+    (False, False, False, True),      # three separate D passes: weight gradients accumulate across them at the join
+    (True, False, True, True)])
+def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d, overlap_wgrad):
     """Two full iterations against the reference's record, in every launch mode: per-layer spectral norm, batched
-    spectral norm, three-stream D-step, and the D-step's three passes stacked into one [3B] pass."""
+    spectral norm, three-stream D-step, the D-step's three passes stacked into one [3B] pass, and the weight gradients
+    on a second stream (ops.weight_grad_stream)."""
     z = load_golden("g8_tiny_e2e")
-    cfg, G, D, step, dev = _build_tiny(z, batched_sn, concurrent_d, stacked_d)
+    cfg, G, D, step, dev = _build_tiny(z, batched_sn, concurrent_d, stacked_d, overlap_wgrad)
     assert step.stacked_d == stacked_d
     for it in (1, 2):
         p = "step%d/" % it
