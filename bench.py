@@ -213,6 +213,13 @@ def main():
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }
         line["roofline"] = conv_roofline(cfg, B, dev)
+        if S == 64:
+            # step-level figures with SURVEY.md section 8(d)'s op-by-op accounting of the REFERENCE graph (7.5 GFLOP and
+            # 356 MB fp32 per image at 64x64): effective rates - fusion that never materialises an intermediate counts
+            step_s = elapsed / args.steps
+            line["step_level"] = {"algorithmic_tflops": round(7.5e9 * B / step_s / 1e12, 2),
+                                  "reference_graph_GBps": round(356e6 * B / step_s / 1e9, 1),
+                                  "frac_of_hbm_peak": round(356e6 * B / step_s / 8.0e12, 4)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -481,7 +481,8 @@ def test_scale_compositions_golden(name, args):
 
 
 # ------------------------------------------------------------------------------------------------ softmax
-@pytest.mark.parametrize("rows,n", [(7, 3), (64 * 16, 64), (96, 256), (33, 1000), (64 * 48, 4096), (5, 65536), (64, 192)])
+@pytest.mark.parametrize("rows,n", [(7, 3), (64 * 16, 64), (96, 256), (33, 1000), (64 * 48, 4096), (5, 65536), (64, 192),
+                                    (9, 1028), (11, 2048), (6, 2500), (5, 3000), (3, 4094), (7, 5000)])
 def test_softmax_rows(rows, n):
     from locate_amd import ops
     torch.manual_seed(rows + n)
