@@ -453,7 +453,7 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 struct GatherCol {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned lane_off;   // bytes
-    unsigned tapmask;    // bit t: tap t reads inside the input for this column (bit 31 is never set)
+    unsigned outside;    // bit t: tap t reads OUTSIDE the input for this column (bit 31 is always set)
 };
 
 __device__ __forceinline__ GatherCol gather_setup(const IgParams& p, const IgPhase& ph, int n, int N) {
@@ -466,22 +466,24 @@ __device__ __forceinline__ GatherCol gather_setup(const IgParams& p, const IgPha
     const int qy = q / ph.QW, qx = q - qy * ph.QW;
     const int iy0 = qy * p.istride, ix0 = qx * p.istride;
     g.lane_off = (unsigned)(4 * ((long long)b * p.in_bs + (long long)iy0 * p.W + ix0));
-    g.tapmask = 0;
+    unsigned inside = 0;
     if (n_ok) {
         for (int t = 0; t < ph.T; ++t) {
             const int th = (t * ph.tw_magic) >> 16, tw = t - th * ph.TW;
             const bool ok = (unsigned)(iy0 + ph.dy0 + ph.dys * th) < (unsigned)p.H &&
                             (unsigned)(ix0 + ph.dx0 + ph.dxs * tw) < (unsigned)p.W;
-            g.tapmask |= (ok ? 1u : 0u) << t;
+            inside |= (ok ? 1u : 0u) << t;
         }
     }
+    g.outside = ~inside;
     return g;
 }
 
 // soff: table entry of row k (bytes, wave-uniform); tap: its tap index (wave-uniform; 31 = never valid)
 __device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsigned tap) {
-    const int m = ((int)(g.tapmask << (31u - tap))) >> 31;          // -1 when the tap is inside the input
-    const unsigned vo = (g.lane_off & (unsigned)m) | (0x80000000u & ~(unsigned)m);
+    // two VALU ops per element: the tap's "outside" bit moves to bit 31 of the offset (lane_off < 2^31), which puts the
+    // access beyond num_records - the buffer load then returns 0 without touching memory (zero padding)
+    const unsigned vo = ((g.outside << (31u - tap)) & 0x80000000u) | g.lane_off;
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rsrc, (int)vo, soff, 0));
 }
 
@@ -675,20 +677,22 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     // weight fragment of this thread: chunk (k-block a_kb, column m0 + a_m) of the three pre-split planes
     const bool a_thread = KB * BM == 256 || tid < KB * BM;
     const int a_kb = a_thread ? tid / BM : 0, a_m = a_thread ? tid % BM : 0;
-    const bool a_ok = a_thread && (m0 + a_m) < ph.ld;
-    const uint4* ap = ph.w3 + (long long)(step0 * KB + a_kb) * ph.ld + (a_ok ? m0 + a_m : 0);
+    // every tile column lies inside the panel: ld = round_up(M, 32) = round_up(M, BM) for the BM pick_bm() chooses (checked by
+    // launch_igemm), and the columns M .. ld - 1 are zero - no masking in the loop
+    const uint4* ap = ph.w3 + (long long)(step0 * KB + a_kb) * ph.ld + (m0 + a_m);
     const long long a_step = (long long)KB * ph.ld, a_plane = ph.w3_plane;
     int kidx = step0 * BK + kgrp * 8;                             // wave-uniform first table row of the next load
 
-    uint4 areg[3];
+    uint4 areg0, areg1, areg2;     // three named registers: as an array this spills to scratch (clang keeps it in memory)
     float breg[8];
     // the offset-table rows are fetched one stage ahead of the gather that uses them: the scalar load's round trip is
     // then off the per-stage critical path (it used to sit in front of every stage's buffer loads)
     i32x8 offs = *reinterpret_cast<const i32x8*>(ph.koff + __builtin_amdgcn_readfirstlane(kidx));                       // s_load_dwordx8
     unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + __builtin_amdgcn_readfirstlane(kidx));   // s_load_dwordx2
     auto issue_loads = [&]() {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) areg[q] = ap[q * a_plane];
+        areg0 = ap[0];
+        areg1 = ap[a_plane];
+        areg2 = ap[2 * a_plane];
         ap += a_step;
 #pragma unroll
         for (int j = 0; j < 8; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
@@ -699,13 +703,9 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     };
     auto store_tiles = [&](int buf) {
         if (a_thread) {
-            const unsigned keep = a_ok ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                uint4 v = areg[q];
-                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
-                As[buf][q][a_kb][a_m] = v;
-            }
+            As[buf][0][a_kb][a_m] = areg0;
+            As[buf][1][a_kb][a_m] = areg1;
+            As[buf][2][a_kb][a_m] = areg2;
         }
         bf16x8 h, m, l;
         float v[8];
@@ -929,6 +929,8 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
     if (p.ksplit > min_kpad / IG_BK) p.ksplit = min_kpad / IG_BK;
     if (p.ksplit < 1) p.ksplit = 1;
     dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
+    for (int i = 0; i < p.nphase; ++i)
+        LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
     if (!path_disabled("bx6")) {
         if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
