@@ -452,6 +452,18 @@ class _BackwardEnd:
     keep = []            # operands of the side-stream kernels: alive until the join, so their memory is not recycled under them
 
 
+def reset_backward_state():
+    """Forget whatever an aborted backward pass (an exception inside the autograd engine never runs its callbacks) left
+    behind; the step driver calls this before every backward()."""
+    _BackwardEnd.scheduled = False
+    _BackwardEnd.side = None
+    _BackwardEnd.pending = []
+    _BackwardEnd.keep = []
+    for entry in _PendingDV.layers.values():
+        entry[5]["k"] = 0
+    _PendingDV.layers = {}
+
+
 def _schedule_backward_end():
     if not _BackwardEnd.scheduled:
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)

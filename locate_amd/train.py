@@ -70,6 +70,7 @@ class TrainStep:
 
     def _backward(self, outputs, grads):
         from . import ops
+        ops.reset_backward_state()
         if not self.overlap_wgrad:
             return torch.autograd.backward(outputs, grads)
         if self._wgrad_side is None:
