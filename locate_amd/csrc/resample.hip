@@ -113,6 +113,23 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restri
     }
 }
 
+// H, W multiples of 2 and W of 4: one thread per four consecutive input-gradient pixels (two pooled values, one 16-byte store)
+__global__ void __launch_bounds__(256) avgpool2_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                               int64_t planes, int H, int W) {
+    const int OW = W / 2, W4 = W / 4;
+    const unsigned n = (unsigned)(planes * H * W4);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)W4), dh((unsigned)H);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, ux, p, iy;
+        dw.divmod(i, t, ux);
+        dh.divmod(t, p, iy);
+        const float2 g = *reinterpret_cast<const float2*>(gy + ((int64_t)p * (H / 2) + (iy >> 1)) * OW + 2 * ux);
+        const float a = g.x * 0.25f, b = g.y * 0.25f;
+        reinterpret_cast<float4*>(gx)[i] = make_float4(a, a, b, b);
+    }
+}
+
 // y[k] = mean(x[r k .. r k + r - 1]) over the flat buffer;  dx[r k + j] = g[k] / r
 __global__ void __launch_bounds__(256) feature_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int64_t n_out, int r) {
@@ -154,7 +171,15 @@ RESAMPLE_ENTRY(locate_upsample2x_bwd, upsample2x_bwd_kernel, planes * H * W)
 // x: [planes, H, W] -> y: [planes, H/2, W/2]
 RESAMPLE_ENTRY(locate_avgpool2_fwd, avgpool2_fwd_kernel, planes * (H / 2) * (W / 2))
 // gy: [planes, H/2, W/2] -> gx: [planes, H, W]   (H, W are the INPUT sizes of the forward)
-RESAMPLE_ENTRY(locate_avgpool2_bwd, avgpool2_bwd_kernel, planes * H * W)
+LOCATE_API int locate_avgpool2_bwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
+    LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_avgpool2_bwd: bad shape");
+    if ((W & 3) == 0 && (H & 1) == 0 && (((uintptr_t)a & 7) | ((uintptr_t)b & 15)) == 0)
+        avgpool2_bwd_vec_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    else
+        avgpool2_bwd_kernel<<<stream_grid(planes * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    LOCATE_LAUNCH_CHECK("locate_avgpool2_bwd");
+    return LOCATE_OK;
+}
 
 LOCATE_API int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, int r, void* stream) {
     LOCATE_REQUIRE(n_out > 0 && r > 0, "locate_feature_pool_fwd: bad shape");

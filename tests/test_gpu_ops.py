@@ -447,6 +447,34 @@ def test_indexing_bit_exact_and_resampling():
     assert_close(t.grad.cpu(), z["expand_dx"], 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (2, 3, 4, 6), (3, 5, 8, 8), (1, 2, 2, 2), (2, 4, 6, 12), (2, 2, 1, 1), (64, 6, 32, 32)])
+def test_resampling_shapes_vs_aten(shape):
+    """Bilinear x2 and 2x2 average pooling (forward and backward) against ATen on odd / even / vectorisable widths: the
+    scalar and the 16-byte-store kernels must agree with the same reference."""
+    from locate_amd import ops
+    torch.manual_seed(sum(shape))
+    x = torch.randn(shape)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    xg = x.to(dev()).requires_grad_(True)
+    yg = ops.upsample2x(xg)
+    yg.backward(g.to(dev()))
+    assert_close(yg.cpu(), yr, 1e-6, "upsample")
+    assert_close(xg.grad.cpu(), xr.grad, 1e-6, "upsample dx")
+    if shape[2] >= 2 and shape[3] >= 2:
+        xr = x.clone().requires_grad_(True)
+        yr = F.avg_pool2d(xr, 2, 2)
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        xg = x.to(dev()).requires_grad_(True)
+        yg = ops.avgpool2(xg)
+        yg.backward(g.to(dev()))
+        assert_close(yg.cpu(), yr, 1e-6, "avgpool")
+        assert torch.equal(xg.grad.cpu(), xr.grad), "avgpool dx"
+
+
 def test_cat_channels():
     from locate_amd import ops
     torch.manual_seed(2)
