@@ -758,9 +758,17 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         mfmas(0, HALF);
         __builtin_amdgcn_sched_barrier(0);
         store_tiles(buf ^ 1);                // tile s + 1
-        issue_loads();                       // tile s + 2
         __builtin_amdgcn_sched_barrier(0);
+        issue_loads();                       // tile s + 2
         mfmas(HALF, NMF);
+        // one vector-memory instruction (and its address arithmetic) in the shadow of every MFMA: the memory pipe takes
+        // ~100 cycles per wave instruction when twelve waves queue on it, the matrix pipe 32 per MFMA
+#pragma unroll
+        for (int k = 0; k < NMF - HALF; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
         __syncthreads();
     }
     // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
