@@ -205,6 +205,26 @@ __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf
     }
 }
 
+// The same exact decomposition by TRUNCATION for the in-loop splits: h = the top 16 bits of x (8 significant bits), r = x - h
+// (exact), m = the top 16 bits of r, l = r - m (at most 8 significant bits left, so its top 16 bits hold all of it).  Bit masks,
+// two subtractions and one byte permute per bf16 pair instead of three conversions and two shifts per element.
+__device__ __forceinline__ void split3_trunc_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
+    const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned q0 = __builtin_bit_cast(unsigned, r0), q1 = __builtin_bit_cast(unsigned, r1);
+    const float l0 = r0 - __builtin_bit_cast(float, q0 & 0xffff0000u), l1 = r1 - __builtin_bit_cast(float, q1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);            // (hi16(v1) << 16) | hi16(v0)
+    m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l0), 0x07060302u);
+}
+
+__device__ __forceinline__ void split3_trunc_x8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+    split3_trunc_pair(v[0], v[1], h.x, m.x, l.x);
+    split3_trunc_pair(v[2], v[3], h.y, m.y, l.y);
+    split3_trunc_pair(v[4], v[5], h.z, m.z, l.z);
+    split3_trunc_pair(v[6], v[7], h.w, m.w, l.w);
+}
+
 // second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k)
 __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int nbx) {
     const float* w = a.out;
@@ -707,14 +727,14 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
             As[buf][1][a_kb][a_m] = areg1;
             As[buf][2][a_kb][a_m] = areg2;
         }
-        bf16x8 h, m, l;
+        uint4 h, m, l;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = breg[j];
-        split3_bf16x8(v, h, m, l);
-        Bs[buf][0][kgrp][ncol] = *reinterpret_cast<uint4*>(&h);
-        Bs[buf][1][kgrp][ncol] = *reinterpret_cast<uint4*>(&m);
-        Bs[buf][2][kgrp][ncol] = *reinterpret_cast<uint4*>(&l);
+        split3_trunc_x8(v, h, m, l);
+        Bs[buf][0][kgrp][ncol] = h;
+        Bs[buf][1][kgrp][ncol] = m;
+        Bs[buf][2][kgrp][ncol] = l;
     };
 
     // Software pipeline: while the matrix pipe works through the first half of a stage's MFMAs, the wave converts and
@@ -1542,7 +1562,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
             unsigned h, m, l;
-            split3_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
+            split3_trunc_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
             Gs[buf][0][sub + 32 * i][wcol] = h;
             Gs[buf][1][sub + 32 * i][wcol] = m;
             Gs[buf][2][sub + 32 * i][wcol] = l;
@@ -1550,7 +1570,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
             unsigned h, m, l;
-            split3_pair(xreg[i].x, xreg[i].y, h, m, l);
+            split3_trunc_pair(xreg[i].x, xreg[i].y, h, m, l);
             Xs[buf][0][sub + 32 * i][wcol] = h;
             Xs[buf][1][sub + 32 * i][wcol] = m;
             Xs[buf][2][sub + 32 * i][wcol] = l;

@@ -30,7 +30,7 @@ for kind, cin, cout, k, s, p, B, H, W in cases:
     sigma = torch.tensor([1.0, 1.0], device=dev)
     wv = torch.zeros(h, device=dev)
     spec = ops.ConvSpec(kind, k, k, s, p, p)
-    y = ops.SNConvFn.apply(xg, wg, u, v, None, sigma, wv, spec, False)
+    y = ops.SNConvFn.apply(xg, wg, u, v, None, sigma, wv, spec)
     y.backward(g.float().to(dev))
 
     def err(a, b):
