@@ -1450,18 +1450,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
                                       // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
                                       // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
-__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    bf16x2 hh, mm, ll;
-    hh[0] = (__bf16)v0; hh[1] = (__bf16)v1;
-    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
-    mm[0] = (__bf16)r0; mm[1] = (__bf16)r1;
-    ll[0] = (__bf16)(r0 - (float)mm[0]); ll[1] = (__bf16)(r1 - (float)mm[1]);
-    h = __builtin_bit_cast(unsigned, hh);
-    m = __builtin_bit_cast(unsigned, mm);
-    l = __builtin_bit_cast(unsigned, ll);
-}
-
 template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;

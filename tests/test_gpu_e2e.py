@@ -173,7 +173,11 @@ def test_full_architectures_step_vs_reference_record(name, S, B, ff, stacked, sw
         for k, w in zip(z[tag + "/post_keys"].tolist(), z[tag + "/post_norms"]):
             if tag == "D" and (k.endswith("weight_u") or k.endswith("weight_v")):
                 continue   # D's u/v were advanced once more by the G-step's D forward after the record point
-            assert abs(float(sd[k].double().norm()) - w) <= 1e-4 * max(w, 1e-6) + 1e-6, (tag, k)
+            # absolute term: 1 % of one learning-rate step.  The first Nadam step moves an element by lr * g / (|g| + 1e-8):
+            # a full +-lr unless |g| is within a few 1e-8 of zero, where the step - and with it the norm of a freshly
+            # initialised all-zero bias (128 elements, norm = 11.3 lr) - carries the gradient's rounding noise
+            lr = cfg.dlr if tag == "D" else cfg.glr
+            assert abs(float(sd[k].double().norm()) - w) <= 1e-4 * max(w, 1e-6) + 0.01 * lr, (tag, k)
 
 
 @pytest.mark.parametrize("S,B,ff,stacked,switches", [
