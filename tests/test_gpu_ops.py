@@ -277,6 +277,11 @@ CONV_CASES = [
     ("conv", 48, 3, 1, 1, 0, 130, 64, 64),    # pointwise, M = 3, two pixels per thread
     ("conv", 50, 64, 1, 1, 0, 128, 32, 34),   # pointwise, ragged K (50), MT = 64
     ("convT", 32, 20, 1, 1, 0, 128, 32, 32),  # pointwise through the adjoint panel, MT = 32
+    # small / unequal output maps (OW = 4, 12, 8; OH != OW), ragged M
+    ("convT", 64, 64, 4, 2, 1, 4, 4, 4),      # OW = 4
+    ("conv", 40, 24, 3, 1, 1, 3, 12, 12),     # OW = 12
+    ("conv", 16, 130, 5, 2, 2, 5, 16, 16),    # OW = 8, ragged M (130), stride 2 with padding
+    ("conv", 24, 32, 3, 1, 1, 2, 4, 8),       # OH != OW
 ]
 
 
