@@ -132,3 +132,44 @@ def test_train_loop_schedule_matches_reference_loop(miniter, diters):
                 ran_g = True
         assert ("g" in out) == ran_g and out["d"] == i
     assert rec.calls == want
+
+
+def test_conv_spec_geometry_for_grouped_layers():
+    """Host-side geometry of the SEPARABLE layers (no GPU): depthwise conv / transposed conv with a channel multiplier and
+    the full-size grouped conv, as handed to locate_dwconv_* / locate_groupdot_*; mismatched shapes are rejected."""
+    from locate_amd.ops import ConvSpec
+    # Conv2d(6, 12, 5, stride 2, pad 2, groups=6): weight [12, 1, 5, 5]
+    geom, out = ConvSpec("conv", 5, 5, 2, 2, 2, mode="depthwise").geometry((4, 6, 16, 16), (12, 1, 5, 5))
+    assert geom == [4, 6, 16, 16, 12, 5, 5, 2, 2, 2, 8, 8] and out == (4, 12, 8, 8)
+    # ConvTranspose2d(6, 12, 4, stride 2, pad 1, groups=6): weight [6, 2, 4, 4]; R's input side is the layer's output
+    geom, out = ConvSpec("convT", 4, 4, 2, 1, 1, mode="depthwise").geometry((4, 6, 8, 8), (6, 2, 4, 4))
+    assert geom == [4, 12, 16, 16, 6, 4, 4, 2, 1, 1, 8, 8] and out == (4, 12, 16, 16)
+    # Conv2d(32, 8, kernel = the 8 x 8 map, groups=8): 8 dot products of 4 * 64 contiguous values per sample
+    geom, out = ConvSpec("conv", 8, 8, 1, 0, 0, mode="groupdot").geometry((5, 32, 8, 8), (8, 4, 8, 8))
+    assert geom[:3] == [5, 8, 256] and out == (5, 8, 1, 1)
+    with pytest.raises(ValueError):
+        ConvSpec("conv", 5, 5, 2, 2, 2, mode="depthwise").geometry((4, 5, 16, 16), (12, 1, 5, 5))     # 12 % 5 != 0
+    with pytest.raises(ValueError):
+        ConvSpec("convT", 4, 4, 2, 1, 1, mode="depthwise").geometry((4, 7, 8, 8), (6, 2, 4, 4))
+    with pytest.raises(ValueError):
+        ConvSpec("conv", 8, 8, 1, 0, 0, mode="groupdot").geometry((5, 32, 8, 8), (8, 4, 4, 4))        # kernel != map
+
+
+@pytest.mark.parametrize("switches", [dict(depth=2), dict(depth=3, feature_multiplier=2), dict(separable=True),
+                                      dict(separable=True, depth=2, feature_multiplier=2)])
+def test_architecture_switches_build_the_reference_key_layout(switches):
+    """state_dict keys and shapes of the mirror under the non-default switches == the reference's (the g15 - g18 records keep
+    the reference's gradient / post-step key lists; construction needs no GPU)."""
+    from conftest import load_golden
+    from locate_amd import Discriminator, Generator, NetConfig
+    name = {(2, 1, False): "g15_depth2_32", (3, 2, False): "g16_depth3_fm2_32", (1, 1, True): "g17_separable_32",
+            (2, 2, True): "g18_separable_depth2_fm2_64"}[(switches.get("depth", 1), switches.get("feature_multiplier", 1),
+                                                          switches.get("separable", False))]
+    size, ff = {"g15_depth2_32": (32, 2), "g16_depth3_fm2_32": (32, 2), "g17_separable_32": (32, 4),
+                "g18_separable_depth2_fm2_64": (64, 2)}[name]
+    z = load_golden(name)
+    cfg = NetConfig(image_size=size, base_feature_factor=ff, **switches)
+    torch.manual_seed(cfg.seed)
+    G, D = Generator(cfg), Discriminator(cfg)
+    assert list(G.state_dict().keys()) == z["G/post_keys"].tolist()
+    assert list(D.state_dict().keys()) == z["D/post_keys"].tolist()
