@@ -3,10 +3,13 @@ ATen calls); replaying them as graphs removes the host from the loop - the MI355
 for a tracing compiler.  Everything the step mutates (weights, spectral-norm u/v, Nadam moments and schedule
 counters) lives in device memory at fixed addresses, so one replay == one more training iteration.
 
-The iteration is captured as FOUR graphs sharing one memory pool (D forward/backward, D Nadam, G
-forward/backward, G Nadam): the optimizer's device tables hold the addresses of the gradient buffers, which
-only exist once the preceding backward has been captured, and building them needs pinned-host staging, which is
-not allowed inside a capture - so they are built eagerly between two captures."""
+The iteration is captured as SIX graphs (D-step generator pass | D forward/backward | D Nadam | G-step generator
+pass | D(fake) + backward | G Nadam; four when the overlapped schedule is off): the optimizer's device tables hold
+the addresses of the gradient buffers, which only exist once the preceding backward has been captured, and building
+them needs pinned-host staging, which is not allowed inside a capture - so they are built eagerly between two
+captures.  Concurrency exists only BETWEEN graphs replayed on different streams (fork/join branches inside one
+captured graph run one after the other on this runtime, tools/graph_branch_probe.py), hence the separate graph for
+the G-step's generator pass."""
 import torch
 
 
