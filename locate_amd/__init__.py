@@ -8,4 +8,5 @@ from .nn import (ActivatedBaseConv, Block, BlockBlock, CatModule, DeepResidualCo
                  SpectralNorm, feature_attention)
 from .models import Discriminator, Generator, get_model, init, parameter_count  # noqa: F401
 from .optim import Nadam  # noqa: F401
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
 from .train import TrainLoop, TrainStep  # noqa: F401

@@ -9,7 +9,10 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the extension shares)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblocate_hip.so")
+# LOCATE_HIP_DEBUG_LIBRARY=1 (read here, on the Python side, once): load the debug variant, the only one that has the
+# LOCATE_DISABLE kernel-flavour switch compiled in (build.py)
+LIB_PATH = os.path.join(_HERE, "csrc", "liblocate_hip_dbg.so" if os.environ.get("LOCATE_HIP_DEBUG_LIBRARY") == "1"
+                        else "liblocate_hip.so")
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

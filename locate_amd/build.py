@@ -10,6 +10,11 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblocate_hip.so")
+# debug variant: the same objects, except that conv.hip is compiled with -DLOCATE_DEBUG_KNOBS (the LOCATE_DISABLE kernel-flavour
+# switch used by tests/test_gpu_ops.py::test_bf16x6_kernels_match_fp32_mfma_kernels and the A/B tools).  Loaded only when
+# LOCATE_HIP_DEBUG_LIBRARY=1 is set before `import locate_amd`; the product library has no such switch compiled in.
+LIB_DBG = os.path.join(CSRC, "liblocate_hip_dbg.so")
+DBG_SOURCES = ["conv.hip"]
 SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "grouped.hip",
            "nadam.hip", "loss.hip"]
 ARCH = "gfx950"
@@ -27,9 +32,9 @@ def _sources():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(LIB_DBG)):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_DBG))
     deps = [os.path.join(CSRC, s) for s in _sources()] + [os.path.join(CSRC, "common.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -53,6 +58,17 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
+    dbg_objs = list(objs)
+    for src in DBG_SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, src.replace(".hip", "_dbg.o"))
+        dbg_objs[dbg_objs.index(os.path.join(CSRC, src.replace(".hip", ".o")))] = obj
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            continue
+        cmd = [hipcc] + flags + ["-DLOCATE_DEBUG_KNOBS", "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src + " (debug)", subprocess.Popen(cmd)))
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed on " + ", ".join(failed))
@@ -60,6 +76,7 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_DBG] + dbg_objs)
     return LIB
 
 

@@ -519,6 +519,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     constexpr int A_PT = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4, "four waves");
     static_assert(BN % 64 == 0 && KPT == 8, "one 8-row group of the offset table per thread and step");
+    static_assert(BK <= IG_TAIL, "panel tail shorter than the prefetch distance (one stage beyond the last)");
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
@@ -655,6 +656,9 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     static_assert(WGM * WGN == 4, "four waves");
     static_assert(BN == 128 && KB * BN == 256, "one gathered fragment (k-block) per thread and stage");
     static_assert(KB * BM <= 256, "at most one weight fragment per thread and stage");
+    // the pipeline issues the loads of two stages beyond the last one (tiles nsteps and nsteps + 1): their weight chunks and
+    // offset-table rows must lie inside the panel's zero tail
+    static_assert(2 * BK <= IG_TAIL && (IG_TAIL % 8) == 0, "panel tail shorter than the prefetch distance");
 
     __shared__ uint4 As[2][3][KB][BM];
     __shared__ uint4 Bs[2][3][KB][BN];
@@ -878,11 +882,17 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     }
 }
 
-// debugging knob for A/B timing inside one process environment: LOCATE_DISABLE=pointwise,...
+// Kernel-flavour switch for A/B timing and for the in-tree cross-check of the bf16 x 6 kernels against the fp32-MFMA ones
+// (LOCATE_DISABLE=bx6,wbx6,pointwise).  Compiled ONLY into the debug variant of the library (liblocate_hip_dbg.so,
+// -DLOCATE_DEBUG_KNOBS): the shipped liblocate_hip.so reads no environment variable, its dispatch depends on its arguments alone.
+#ifdef LOCATE_DEBUG_KNOBS
 static bool path_disabled(const char* name) {
     static const char* env = getenv("LOCATE_DISABLE");
     return env != nullptr && strstr(env, name) != nullptr;
 }
+#else
+static constexpr bool path_disabled(const char*) { return false; }
+#endif
 
 static bool pointwise_ok(const IgParams& p) {
     if (p.nphase != 1 || path_disabled("pointwise")) return false;

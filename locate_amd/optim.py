@@ -26,9 +26,42 @@ class Nadam(torch.optim.Optimizer):
             st["sched"] = torch.tensor([0.0, 1.0], dtype=torch.float64, device=p.device)   # step, m_schedule
         return st
 
+    # ---- checkpointing --------------------------------------------------------------------------------------------
+    # torch.optim.Optimizer.load_state_dict casts every floating-point state tensor to the parameter's dtype, which would
+    # turn the float64 (step, m_schedule) pair into float32 - the schedule kernel reads it as two doubles.  The state is
+    # restored to float64 (from the checkpoint's own values, which are exact: a step count and a product of a few factors)
+    # and the device tables, which hold the OLD state buffers' addresses, are dropped.
+    def load_state_dict(self, state_dict):
+        sched = {}
+        for idx, st in state_dict.get("state", {}).items():
+            if "sched" in st:
+                sched[idx] = st["sched"].detach().to("cpu", torch.float64).clone()
+        super().load_state_dict(state_dict)
+        order = [p for group in self.param_groups for p in group["params"]]
+        ids = [i for group in state_dict["param_groups"] for i in group["params"]]
+        for idx, p in zip(ids, order):
+            st = self.state.get(p)
+            if st and idx in sched:
+                st["sched"] = sched[idx].to(p.device)
+        self._restore_invariants()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._restore_invariants()
+
+    def _restore_invariants(self):
+        self._tables = {}
+        for p, st in self.state.items():
+            if "sched" in st and st["sched"].dtype != torch.float64:
+                st["sched"] = st["sched"].to(torch.float64)
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st and not st[k].is_contiguous():
+                    st[k] = st[k].contiguous()
+
     def _table(self, plist):
-        """Device tables for one set of (parameter, gradient) buffers; cached on the buffer addresses."""
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        """Device tables for one set of (parameter, gradient, state) buffers; cached on ALL the addresses a record holds."""
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(self._state_for(p)[k].data_ptr() for k in ("exp_avg", "exp_avg_sq", "sched"))
+                    for p in plist)
         tab = self._tables.get(key)
         if tab is not None:
             return tab

@@ -2,8 +2,8 @@
 
 TEST INFRASTRUCTURE - never imported by the product (`locate_amd/`), by `bench.py`'s timed
 region or on the GPU box (the reference tree does not exist there).  It is used by
-`oracle/gen_golden.py` to emit the fixtures under `tests/golden/` and by the optional
-`tests/test_oracle_vs_reference.py` (skipped when /root/reference is absent).
+`oracle/gen_golden.py` alone, to emit the fixtures under `tests/golden/` (the oracle itself is then checked against
+those fixtures by `tests/test_oracle_golden.py`, which needs no reference tree).
 
 What it does:
   * never writes bytecode into the read-only reference tree;

@@ -166,7 +166,7 @@ def test_full_architectures_step_vs_reference_record(name, S, B, ff, stacked, sw
             # d(gamma) = sum x^2 g over a whole activation is a scalar with heavy cancellation: at batch 2 even the CPU
             # oracle - the same ATen kernels as the reference, merely composed differently - deviates by 6.5e-5 on the
             # generator's gammas (1e-6 elsewhere); tools/full_arch_errors.py lists the per-tensor deviations
-            tol = 2e-3 if k.endswith("gamma") else 5e-4
+            tol = 3e-4 if k.endswith("gamma") else 5e-4
             assert abs(got[k] - want[k]) <= tol * max(want[k], 1e-3 * scale), (tag, k, got[k], want[k])
     for tag, net in (("D", D), ("G", G)):
         sd = net.state_dict()
@@ -233,7 +233,7 @@ def test_step_vs_oracle_on_unusual_shapes(S, B, ff, stacked, switches):
         assert sorted(got) == sorted(ref), tag
         for k, v in ref.items():
             # d(gamma) = sum x^2 g: a scalar with heavy cancellation (see test_full_architectures_step_vs_reference_record)
-            assert_close(got[k], v, 2e-3 if k.endswith("gamma") else 3e-4, tag + " grad " + k)
+            assert_close(got[k], v, 3e-4, tag + " grad " + k)
     for k, v in want["d_post_step"].items():
         assert_step_close(rec["d_post"][k], v, cfg.dlr, 1, "D post " + k)
     gsd = G.state_dict()

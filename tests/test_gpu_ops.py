@@ -282,6 +282,11 @@ CONV_CASES = [
     ("conv", 40, 24, 3, 1, 1, 3, 12, 12),     # OW = 12
     ("conv", 16, 130, 5, 2, 2, 5, 16, 16),    # OW = 8, ragged M (130), stride 2 with padding
     ("conv", 24, 32, 3, 1, 1, 2, 4, 8),       # OH != OW
+    # boundaries of the K pipeline (the kernels prefetch two stages past the last one into the panel's zero tail):
+    ("conv", 272, 256, 3, 1, 1, 8, 16, 16),   # K = 2448 = 16 * 153 exactly, 19 uneven K splits (17 x 9 stages + 1 x 1)
+    ("conv", 260, 64, 3, 1, 1, 2, 8, 8),      # ragged K = 2340, split count capped at 64: trailing splits own no stage
+    ("convT", 296, 64, 4, 2, 1, 2, 4, 4),     # adjoint phases with K = 1184 = Kpad exactly (no padding rows before the tail)
+    ("conv", 128, 128, 1, 1, 0, 4, 8, 8),     # K = Kpad = 128: 8 stages, the split threshold
 ]
 
 
@@ -657,13 +662,14 @@ torch.save(out, sys.argv[1])
 
 def test_bf16x6_kernels_match_fp32_mfma_kernels(tmp_path):
     """The default contractions (exact three-way bf16 splits, six bf16 MFMAs) against the fp32-input MFMA kernels kept
-    in the library as the cross-check (LOCATE_DISABLE=bx6,wbx6, read once per process - hence the two child processes)."""
+    in the DEBUG variant of the library as the cross-check (liblocate_hip_dbg.so, LOCATE_DISABLE=bx6,wbx6 read once per
+    process - hence the two child processes; the product library has no such switch)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("bx6", {}), ("f32", {"LOCATE_DISABLE": "bx6,wbx6"})):
+    for tag, env in (("bx6", {}), ("f32", {"LOCATE_HIP_DEBUG_LIBRARY": "1", "LOCATE_DISABLE": "bx6,wbx6"})):
         path = str(tmp_path / (tag + ".pt"))
         subprocess.check_call([sys.executable, "-c", _XCHECK % root, path], env=dict(os.environ, **env))
         res[tag] = torch.load(path, weights_only=True)

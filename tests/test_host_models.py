@@ -173,3 +173,59 @@ def test_architecture_switches_build_the_reference_key_layout(switches):
     G, D = Generator(cfg), Discriminator(cfg)
     assert list(G.state_dict().keys()) == z["G/post_keys"].tolist()
     assert list(D.state_dict().keys()) == z["D/post_keys"].tolist()
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """save_checkpoint writes the reference's netG.torch / netD.torch (plain state_dicts, main.py:235-236) plus the noise
+    map the reference forgets (models.py:59); load_checkpoint restores all of it with weights_only loads, and also
+    accepts a folder written by the reference (no side file)."""
+    from locate_amd import load_checkpoint, save_checkpoint
+    cfg = NetConfig(image_size=32, base_feature_factor=1)
+    torch.manual_seed(1)
+    G, D = Generator(cfg), Discriminator(cfg)
+    files = save_checkpoint(str(tmp_path), G, D)
+    assert sorted(os.path.basename(f) for f in files) == ["netD.torch", "netG.extra.torch", "netG.torch"]
+    raw = torch.load(os.path.join(tmp_path, "netG.torch"), weights_only=True)
+    assert list(raw.keys()) == list(G.state_dict().keys()) and "noise" not in raw      # exactly the reference's file
+    torch.manual_seed(2)
+    G2, D2 = Generator(cfg), Discriminator(cfg)
+    assert not torch.equal(G2.noise, G.noise)
+    noise_obj = G2.noise
+    rec = load_checkpoint(str(tmp_path), G2, D2)
+    assert rec["noise_restored"] and G2.noise is noise_obj and torch.equal(G2.noise, G.noise)
+    for a, b in ((G, G2), (D, D2)):
+        for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert k == k2 and torch.equal(v, v2), k
+    # a reference-written folder: the g8 record's initial state_dicts saved the way main.py:235-236 does
+    z = load_golden("g8_tiny_e2e")
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    for tag, name in (("G", "netG.torch"), ("D", "netD.torch")):
+        torch.save({k[len(tag + "/sd0/"):]: torch.as_tensor(z[k]) for k in z.files if k.startswith(tag + "/sd0/")}, ref_dir / name)
+    rec = load_checkpoint(str(ref_dir), G2, D2)
+    assert not rec["noise_restored"]
+    key = "conv_block.block_0.res_module_i.gamma"
+    assert torch.equal(G2.state_dict()[key], torch.as_tensor(z["G/sd0/" + key]))
+
+
+def test_nadam_state_dict_roundtrip_keeps_the_schedule_in_float64(tmp_path):
+    """torch's Optimizer.load_state_dict casts float state to the parameter dtype; the (step, m_schedule) pair must come
+    back as float64 (the schedule kernel reads two doubles) and the cached device tables must be dropped."""
+    from locate_amd import Nadam
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    opt = Nadam(ps, lr=1e-3, betas=(0.5, 0.9))
+    for p in ps:
+        st = opt._state_for(p)
+        st["sched"][0], st["sched"][1] = 3.0, 0.123456789012345678
+        st["exp_avg"].normal_()
+    opt._tables["stale"] = object()
+    path = tmp_path / "opt.torch"
+    torch.save(opt.state_dict(), path)
+    opt2 = Nadam([torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))], lr=1e-3, betas=(0.5, 0.9))
+    opt2._tables["stale"] = object()
+    opt2.load_state_dict(torch.load(path, weights_only=True))
+    assert opt2._tables == {}
+    for p, q in zip(ps, opt2.param_groups[0]["params"]):
+        a, b = opt.state[p], opt2.state[q]
+        assert b["sched"].dtype == torch.float64 and torch.equal(a["sched"], b["sched"])
+        assert torch.equal(a["exp_avg"], b["exp_avg"])

@@ -1,5 +1,5 @@
 """Error of the conv forward / data gradient / weight gradient against a float64 CPU reference (normalised max error).
-Run once per kernel flavour: LOCATE_DISABLE=bx6,wbx6 (fp32 MFMA) vs default (bf16 x 6)."""
+Run once per kernel flavour: LOCATE_HIP_DEBUG_LIBRARY=1 LOCATE_DISABLE=bx6,wbx6 (fp32 MFMA, debug library only) vs default (bf16 x 6)."""
 import os
 import sys
 

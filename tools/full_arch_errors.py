@@ -1,5 +1,5 @@
 """Worst relative deviations of per-tensor gradient norms from the reference's record for a full architecture
-(tests/golden/g11..g14).  usage: python tools/full_arch_errors.py g12_config3_128 128 2 8   [LOCATE_DISABLE=... to pick kernels]"""
+(tests/golden/g11..g14).  usage: python tools/full_arch_errors.py g12_config3_128 128 2 8   [LOCATE_HIP_DEBUG_LIBRARY=1 LOCATE_DISABLE=... to pick kernels]"""
 import os
 import sys
 
