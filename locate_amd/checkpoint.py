@@ -7,7 +7,9 @@ reproduce its own samples.  Here:
 
   * `netG.torch` / `netD.torch` hold exactly the reference's `state_dict()` (same keys, shapes, dtypes), so a file written
     by the reference loads here and a file written here loads into the reference (`load_state_dict(torch.load(...))`);
-  * `netG.extra.torch` (a side file, so that `netG.torch` stays reference-compatible) holds `noise`;
+  * `netG.extra.torch` (a side file, so that `netG.torch` stays reference-compatible) holds `noise` and one flag: whether
+    the discriminator's spectral-norm u/v are trainable yet (the reference's `dis.requires_grad_(True)` after the first
+    G-step makes them so, main.py:172 - a piece of training state that `state_dict()` cannot carry);
   * `optG.torch` / `optD.torch` (optional) hold the Nadam states (`step`/`m_schedule` as float64, the two moments);
   * every load uses `weights_only=True`: nothing from a checkpoint file is ever executed.
 """
@@ -49,7 +51,8 @@ def save_checkpoint(folder, gen, dis, gen_opt=None, dis_opt=None):
         torch.cuda.synchronize()           # the optimizer / graph replays write the weights through raw pointers
     put(G_FILE, _cpu(gen.state_dict()))
     put(D_FILE, _cpu(dis.state_dict()))
-    put(G_EXTRA_FILE, {"noise": gen.noise.detach().to("cpu").clone()})
+    uv = [p.requires_grad for n, p in dis.named_parameters() if n.endswith(("weight_u", "weight_v"))]
+    put(G_EXTRA_FILE, {"noise": gen.noise.detach().to("cpu").clone(), "dis_uv_trainable": bool(uv) and all(uv)})
     if gen_opt is not None:
         put(G_OPT_FILE, _cpu_tree(gen_opt.state_dict()))
     if dis_opt is not None:
@@ -65,12 +68,16 @@ def load_checkpoint(folder, gen, dis, gen_opt=None, dis_opt=None, strict=True):
     """Loads what save_checkpoint wrote - or what the reference wrote (then there is no netG.extra.torch: the noise map
     keeps its current value and `noise_restored` is False in the returned record).  Weight panels are re-packed lazily
     (load_state_dict bumps the parameters' version counters); optimizer files are optional."""
-    rec = {"noise_restored": False, "gen_opt_restored": False, "dis_opt_restored": False}
+    rec = {"noise_restored": False, "gen_opt_restored": False, "dis_opt_restored": False, "dis_uv_trainable": False}
     gen.load_state_dict(_load(os.path.join(folder, G_FILE)), strict=strict)
     dis.load_state_dict(_load(os.path.join(folder, D_FILE)), strict=strict)
     extra = os.path.join(folder, G_EXTRA_FILE)
     if os.path.exists(extra):
-        noise = _load(extra)["noise"]
+        side = _load(extra)
+        noise = side["noise"]
+        if side.get("dis_uv_trainable", False):
+            dis.requires_grad_(True)       # main.py:172 has already run in the checkpointed training state
+            rec["dis_uv_trainable"] = True
         if tuple(noise.shape) != tuple(gen.noise.shape):
             raise ValueError("checkpoint noise map %s does not fit the generator's %s" % (tuple(noise.shape), tuple(gen.noise.shape)))
         with torch.no_grad():

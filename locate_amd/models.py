@@ -6,26 +6,16 @@ import torch
 from torch import nn
 
 from .config import get_default
-from .nn import BlockBlock, DeepResidualConv, InPlaceNorm, ResModule, Scale, SpectralNorm, _identity
-from . import ops
-
-
-def _quadnorm(number):
-    return number // 4 * 4
+from .nn import BlockBlock, DeepResidualConv, ResModule, Scale, SpectralNorm, _Bound, _identity
+from . import arch, ops
 
 
 def generator_features(cfg):
-    """[Z, w_{n-1}, ..., w_0] with w_idx = quadnorm(GEN_FEATURES * FACTOR^(idx - n)) (models.py:16-22,43-52)."""
-    n = cfg.layers - 1
-    widths = [_quadnorm(int(cfg.gen_features * cfg.factor ** (idx - n))) for idx in range(n - 1, -1, -1)]
-    return [cfg.input_vector_z] + widths
+    return arch.generator_widths(cfg)
 
 
 def discriminator_features(cfg):
-    """[w_0, ..., w_{n-1}, w_{n-1}] with w_idx = quadnorm(DIS_FEATURES * FACTOR^(idx + 1 - n)) (models.py:25-31,76-78)."""
-    n = cfg.layers - 1
-    widths = [_quadnorm(int(cfg.dis_features * cfg.factor ** ((idx + 1) - n))) for idx in range(n)]
-    return widths + [widths[-1]]
+    return arch.discriminator_widths(cfg)
 
 
 class SpectralNormBatch:
@@ -109,6 +99,14 @@ class SpectralNormBatch:
 class _NetBase(nn.Module):
     batched_spectral_norm = False   # see SpectralNormBatch; off by default (per-layer update inside each layer)
 
+    def adopt(self):
+        """Gives the network its own ops.Runtime (stacked-call count, backward-pass deferrals) and points every layer that
+        needs one at it - called at the end of the constructors.  Two networks therefore never share mutable host state."""
+        object.__setattr__(self, "runtime", ops.Runtime())
+        for m in self.modules():
+            if isinstance(m, _Bound):
+                object.__setattr__(m, "runtime", self.runtime)
+
     def _batch(self):
         if getattr(self, "_sn_batch", None) is None:
             object.__setattr__(self, "_sn_batch", SpectralNormBatch(self))
@@ -153,6 +151,7 @@ class Generator(_NetBase):
         self.g_in = feature_list[0]
         # a plain tensor like in the reference (models.py:59): not a Parameter, not in state_dict()
         self.noise = torch.randn(1, cfg.input_vector_z, 2, 2)
+        self.adopt()
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -178,6 +177,7 @@ class Discriminator(_NetBase):
         block_block = BlockBlock(len(strides), cfg.image_size // 2, feature_list, strides, False, cfg=cfg)
         head = DeepResidualConv(block_block.out_features, 1, False, 1, False, 2, 1, cfg=cfg)   # END_LAYER = 1
         self.main = nn.Sequential(stem, block_block, head)
+        self.adopt()
 
     def forward(self, function_input, stacked=1):
         """stacked = k > 1: `function_input` stacks k independent calls along the batch (k equal slices); the result
@@ -186,27 +186,25 @@ class Discriminator(_NetBase):
         self._sn_prologue(stacked)
         if stacked == 1:
             return self.main(function_input)
-        with ops.stacked_calls(stacked):
+        with self.runtime.stacked_calls(stacked):
             return self.main(function_input)
 
 
 def init(module):
-    """libs/utils.py:116-130 as it actually behaves when applied before the first forward: wrapped convs have no
-    `.weight` yet, so only norm weights (~U(0.998, 1.002)) and biases (0) are touched."""
-    if "norm" not in module.__class__.__name__.lower():
-        try:
-            nn.init.orthogonal_(module.weight.data)
-        except AttributeError:
-            pass
-    else:
-        try:
-            nn.init.uniform_(module.weight.data, 0.998, 1.002)
-        except AttributeError:
-            pass
-    try:
-        nn.init.constant_(module.bias.data, 0)
-    except AttributeError:
-        pass
+    """Per-module initialiser for `model.apply` (libs/utils.py:116-130), as it behaves when applied before the first
+    forward - which is when `get_model` applies it: a module whose class name contains "norm" gets its weight drawn from
+    U(0.998, 1.002), any other module that owns a `weight` an orthogonal one, and every `bias` is zeroed.  Spectral-norm
+    wrapped convs / linears expose no `weight` then (it has become `weight_bar`), so in the networks of this package only
+    InPlaceNorm weights and the few biases are touched; the wrapped weights keep torch's default initialisation."""
+    weight = getattr(module, "weight", None)
+    if torch.is_tensor(weight):
+        if "norm" in type(module).__name__.lower():
+            nn.init.uniform_(weight.data, 0.998, 1.002)
+        else:
+            nn.init.orthogonal_(weight.data)
+    bias = getattr(module, "bias", None)
+    if torch.is_tensor(bias):
+        nn.init.constant_(bias.data, 0)
 
 
 def get_model(model, learning_rate, device, cfg=None):

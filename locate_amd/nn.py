@@ -3,6 +3,12 @@ signatures, parameter names and therefore the same `state_dict()` key layout), c
 `locate_amd.ops`.  torch.nn.Conv2d / ConvTranspose2d / Conv1d / Linear objects are used only as parameter
 containers (shape, default initialisation, hyper-parameters): their own forward is never called.
 
+What is fixed by the drop-in contract (and pinned by tests/golden/g10_init_*.npz): attribute names that become
+`state_dict()` keys, the order in which parameters are registered, and the order in which constructors draw from the
+RNG.  Everything else - how a stack is described, how the style chain is laid out, how a forward walks its parts - is
+this package's own: a network is first DESCRIBED (`locate_amd/arch.py`: a list of `Stage` records with the widths of the
+style chain as data) and then built from the description.
+
 Reference interface -> here
     libs/activation.py:42-51   RootTanhModule / NonLinear
     libs/inplace_norm.py:34-56 InPlaceNorm, Norm
@@ -18,12 +24,18 @@ Reference interface -> here
 import torch
 from torch import nn
 
-from . import ops
+from . import arch, ops
 from .config import get_default
 
 
 def _identity(x):
     return x
+
+
+class _Bound(nn.Module):
+    """A layer whose kernels need the owning network's runtime state (ops.Runtime: stacked calls, backward-pass deferrals).
+    `runtime` is set by the network after construction (models._NetBase.adopt); stand-alone layers use the default one."""
+    runtime = None
 
 
 class RootTanhModule(nn.Module):
@@ -34,16 +46,18 @@ class RootTanhModule(nn.Module):
 NonLinear = RootTanhModule
 
 
-class InPlaceNorm(nn.Module):
+class InPlaceNorm(_Bound):
     """Global-statistics normalisation + per-channel affine (or per-sample style scale)."""
 
     def __init__(self, features=1, dim=2):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones((1, features, *[1] * dim)))
-        self.bias = nn.Parameter(torch.zeros((1, features, *[1] * dim)))
+        shape = (1, features) + (1,) * dim
+        self.weight = nn.Parameter(torch.ones(shape))
+        self.bias = nn.Parameter(torch.zeros(shape))
 
     def forward(self, function_input, scale=None, with_act=False):
-        return ops.inplace_norm(function_input, self.weight if scale is None else scale, self.bias, with_act)
+        gain = self.weight if scale is None else scale
+        return ops.inplace_norm(function_input, gain, self.bias, with_act, self.runtime)
 
 
 class Norm(nn.Module):
@@ -53,16 +67,17 @@ class Norm(nn.Module):
         self.module = module
 
     def forward(self, function_input, scale=None):
-        if getattr(self.module, "starts_with_activation", False):
-            # norm + the wrapped conv stage's leading RootTanh in one kernel
-            return self.module(self.i_norm(function_input, scale, with_act=True), pre_activated=True)
-        return self.module(self.i_norm(function_input, scale))
+        fused = bool(getattr(self.module, "starts_with_activation", False))
+        normed = self.i_norm(function_input, scale, with_act=fused)      # fused: norm + the stage's leading RootTanh, one kernel
+        return self.module(normed, pre_activated=True) if fused else self.module(normed)
 
 
-class SpectralNorm(nn.Module):
+class SpectralNorm(_Bound):
     """Wraps a torch.nn conv / linear: every forward runs one power iteration on (weight_u, weight_v) in place
     and applies the layer with weight_bar / sigma.  Parameters live on the wrapped module under the reference's
     names (`module.weight_bar|weight_u|weight_v`)."""
+
+    _SUFFIXES = ("_u", "_v", "_bar")
 
     def __init__(self, module, name="weight", power_iterations=1):
         super().__init__()
@@ -72,25 +87,25 @@ class SpectralNorm(nn.Module):
         self.name = name
         self.power_iterations = power_iterations
         self._pre = None          # (sigma, wv) left by a batched update for the next forward
-        if not self._made_params():
-            self._make_params()
+        if not all(hasattr(module, name + s) for s in self._SUFFIXES):
+            self._adopt_weight()
 
-    def _made_params(self):
-        return all(hasattr(self.module, self.name + s) for s in ("_u", "_v", "_bar"))
+    def _adopt_weight(self):
+        """Moves `module.<name>` to `<name>_bar` and adds the power-iteration state: u (one entry per row of the weight
+        seen as a matrix [shape[0], rest]) and v (one per column), each one N(0, 1) draw scaled to unit length, u drawn
+        before v, registered in the order u, v, bar - after whatever the layer already holds (its bias)."""
+        layer, stem = self.module, self.name
+        weight = layer._parameters.pop(stem)
+        rows = weight.shape[0]
+        cols = weight.numel() // rows
 
-    def _make_params(self):
-        w = getattr(self.module, self.name)
-        height = w.data.shape[0]
-        width = w.data.numel() // height
-        u = nn.Parameter(w.data.new(height).normal_(0, 1), requires_grad=False)
-        v = nn.Parameter(w.data.new(width).normal_(0, 1), requires_grad=False)
-        u.data = u.data / (u.data.norm() + 1e-12)
-        v.data = v.data / (v.data.norm() + 1e-12)
-        w_bar = nn.Parameter(w.data)
-        del self.module._parameters[self.name]
-        self.module.register_parameter(self.name + "_u", u)
-        self.module.register_parameter(self.name + "_v", v)
-        self.module.register_parameter(self.name + "_bar", w_bar)
+        def unit_vector(n):
+            t = weight.data.new_empty(n).normal_(0, 1)
+            return nn.Parameter(t / (t.norm() + 1e-12), requires_grad=False)
+
+        state = {"_u": unit_vector(rows), "_v": unit_vector(cols), "_bar": nn.Parameter(weight.data)}
+        for suffix in self._SUFFIXES:
+            layer.register_parameter(stem + suffix, state[suffix])
 
     # geometry of the wrapped layer in terms of ops.ConvSpec ------------------------------------------------
     def _plan(self, x):
@@ -146,42 +161,47 @@ class SpectralNorm(nn.Module):
     def forward(self, x):
         m = self.module
         x4, w4, spec, restore = self._plan(x)
-        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, self.take_pre())
+        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, self.take_pre(), self.runtime)
         return restore(y)
 
 
-class CatModule(nn.Module):
+class _TwoBranch(nn.Module):
+    """A skip branch and a layer branch over the same input (optionally a different input and a style scale for the layer
+    branch); subclasses say how the two results merge.  Attribute names are the reference's (they are state_dict keys)."""
+
     def __init__(self, residual_module, layer_module):
         super().__init__()
         self.residual_module = residual_module
         self.layer_module = layer_module
 
+    def _run(self, function_input, layer_input, scale):
+        skip = self.residual_module(function_input)
+        feed = function_input if layer_input is None else layer_input
+        branch = self.layer_module(feed) if scale is None else self.layer_module(feed, scale)
+        return skip, branch
+
+
+class CatModule(_TwoBranch):
+    """Channel concatenation [skip, layer] (libs/merge.py:4-16)."""
+
     def forward(self, function_input, layer_input=None, scale=None):
-        args = [function_input if layer_input is None else layer_input]
-        if scale is not None:
-            args.append(scale)
-        return ops.cat_channels(self.residual_module(function_input), self.layer_module(*args))
+        return ops.cat_channels(*self._run(function_input, layer_input, scale))
 
 
-class ResModule(nn.Module):
-    """out = (gamma * layer(x) + 1) * residual(x) with a scalar gamma = (+-1) + m + 1."""
+class ResModule(_TwoBranch):
+    """out = (gamma * layer(x) + 1) * skip(x) with one scalar gamma, initialised to (+-1) + m + 1 (the sign is the
+    orthogonal initialisation of a 1 x 1 matrix: one RNG draw; libs/merge.py:46-62)."""
 
     def __init__(self, residual_module, layer_module, m=0):
-        super().__init__()
-        self.residual_module = residual_module
-        self.layer_module = layer_module
-        self.gamma = nn.Parameter(torch.ones((1, 1)))
-        nn.init.orthogonal_(self.gamma.data)
-        self.gamma.data.add_(m + 1)
+        super().__init__(residual_module, layer_module)
+        gamma = torch.ones((1, 1))
+        nn.init.orthogonal_(gamma)
+        self.gamma = nn.Parameter(gamma + (m + 1))
 
     def forward(self, function_input, layer_input=None, scale=None):
-        args = [function_input if layer_input is None else layer_input]
-        if scale is not None:
-            args.append(scale)
-        res = self.residual_module(function_input)
-        layer_out = self.layer_module(*args)
-        compact = getattr(layer_out, "_locate_compact", None)   # un-expanded [B, C, 1, 1] source (see Expand)
-        return ops.residual_gate(res, layer_out if compact is None else compact, self.gamma)
+        skip, branch = self._run(function_input, layer_input, scale)
+        compact = getattr(branch, "_locate_compact", None)     # un-expanded [B, C, 1, 1] source (see Expand)
+        return ops.residual_gate(skip, branch if compact is None else compact, self.gamma)
 
 
 class FeaturePooling(nn.Module):
@@ -259,30 +279,24 @@ class ChannelSoftmax(nn.Module):
 
 
 def feature_attention(in_size, features, dim=2, cfg=None):
+    """Channel gate of a block (libs/attention.py:9-37): squeeze the S x S map to one value per bottleneck channel, expand
+    back to `features` channels, softmax over the channels, broadcast over the map.  Built from `arch.squeeze_plan` - a
+    list of conv descriptions - as an nn.Sequential whose positions are the reference's (they are state_dict keys)."""
     cfg = cfg or get_default()
     if dim != 2:
         raise NotImplementedError("dim = 2 only")
-    bfeatures = features // cfg.bottleneck
-    layers = []
-    input_features = features
-    min_features = min(input_features, bfeatures)
-    if cfg.separable and input_features % min_features == 0 and bfeatures % min_features == 0:
-        # one grouped full-size conv instead of the (S x 1), (1 x S) pair - and no RootTanh after it (attention.py:15-21)
-        layers.append(SpectralNorm(nn.Conv2d(input_features, bfeatures, kernel_size=[in_size] * dim, bias=False,
-                                             groups=min_features)))
-    else:
-        for i in range(dim):
-            kernel_size = [1] * dim
-            kernel_size[i] = in_size
-            layers.extend([SpectralNorm(nn.Conv2d(input_features, bfeatures, kernel_size=kernel_size, bias=False)), NonLinear()])
-            input_features = bfeatures
-    layers.extend([SpectralNorm(nn.Conv2d(bfeatures, features, kernel_size=1, bias=False)), ChannelSoftmax(),
-                   Expand(-1, features, *([in_size] * dim))])
-    return nn.Sequential(*layers)
+    parts = []
+    for conv in arch.squeeze_plan(in_size, features, cfg):
+        parts.append(SpectralNorm(nn.Conv2d(conv.cin, conv.cout, kernel_size=conv.kernel, bias=False, groups=conv.groups)))
+        if conv.activated:
+            parts.append(NonLinear())
+    parts += [ChannelSoftmax(), Expand(-1, features, *([in_size] * dim))]
+    return nn.Sequential(*parts)
 
 
 class SelfAttention(nn.Module):
-    """softmax over the N = H*W positions of conv1x1(RootTanh(conv1x1(x))) - a gate, not a QK^T attention."""
+    """Position gate: softmax over the N = H*W positions of conv1x1(RootTanh(conv1x1(x))), per (sample, channel) - not a
+    QK^T attention (libs/attention.py:40-54)."""
 
     def __init__(self, features):
         super().__init__()
@@ -291,10 +305,11 @@ class SelfAttention(nn.Module):
         self.conv_1 = SpectralNorm(nn.Conv1d(features, features, 1, bias=False))
 
     def forward(self, function_input):
-        batch, features, *size = function_input.size()
-        out = function_input.reshape(batch, features, -1)
-        out = ops.softmax_lastdim(self.conv_1(self.nlin_0(self.conv_0(out))))
-        return out.view(batch, features, *size)
+        shape = function_input.shape
+        rows = function_input.reshape(shape[0], shape[1], -1)          # [B, C, N]
+        for part in (self.conv_0, self.nlin_0, self.conv_1):
+            rows = part(rows)
+        return ops.softmax_lastdim(rows).view(shape)
 
 
 class ActivatedBaseConv(nn.Module):
@@ -315,11 +330,10 @@ class ActivatedBaseConv(nn.Module):
 
 
 class DeepResidualConv(nn.Module):
-    """A chain of `depth` ActivatedBaseConv stages (libs/conv.py:27-72).  Stage 0 carries the stride / transposition with
-    kernel 2*stride + (0 if transposed else 1) and maps to the bottleneck width when depth > 1; the depth - 2 middle
-    stages (5x5, bottleneck -> bottleneck) and the last one (5x5, bottleneck -> out) are wrapped in Norm from the second
-    one on and in a ResModule(m=1) whenever their widths agree.  (The reference passes its conv class in the `residual`
-    slot of its helper - a truthy value - so every stage after the first is residual.)"""
+    """A chain of `depth` ActivatedBaseConv stages (libs/conv.py:27-72), built from `arch.conv_chain`: stage 0 carries the
+    stride / transposition with kernel 2*stride + (0 if transposed else 1) and maps to the bottleneck width when
+    depth > 1; the later stages are 5x5, wrapped in Norm from the second one on and in a ResModule(m=1) whenever their
+    widths agree."""
     starts_with_activation = True
 
     def __init__(self, in_features, out_features, transpose, stride, use_bottleneck=True, dim=2, depth=1, cfg=None):
@@ -327,34 +341,21 @@ class DeepResidualConv(nn.Module):
         if dim != 2:
             raise NotImplementedError("dim = 2 only")
         cfg = cfg or get_default()
-        min_features = min(in_features, out_features)
-        if use_bottleneck and max(in_features, out_features) // min_features < cfg.bottleneck:
-            min_features //= cfg.bottleneck
-        if depth > 1 and min_features < 1:
-            raise ValueError("DeepResidualConv(%d -> %d, depth %d): the bottleneck width is 0" % (in_features, out_features, depth))
-        kernel = stride * 2 + int(not transpose)
-        pad = max(kernel // 2 - stride // 2, 0) if transpose else kernel // 2
         self.layers = []
-
-        def add_conv(cin, cout, residual, normalize, conv=nn.Conv2d, **kw):
-            layer = ActivatedBaseConv(cin, cout, conv, cfg=cfg, **kw)
-            if normalize:
-                layer = Norm(cin, layer, dim)
-            if residual and cin == cout:
+        for link in arch.conv_chain(in_features, out_features, transpose, stride, use_bottleneck, depth, cfg):
+            conv_cls = nn.ConvTranspose2d if link.transposed else nn.Conv2d
+            layer = ActivatedBaseConv(link.cin, link.cout, conv_cls, kernel=link.kernel, stride=link.stride, pad=link.pad, cfg=cfg)
+            if link.normalized:
+                layer = Norm(link.cin, layer, dim)
+            if link.residual:
                 layer = ResModule(_identity, layer, m=1)
             setattr(self, "conv_%d" % len(self.layers), layer)
             self.layers.append(layer)
 
-        add_conv(in_features, min_features if depth > 1 else out_features, False, False,
-                 conv=nn.ConvTranspose2d if transpose else nn.Conv2d, kernel=kernel, stride=stride, pad=pad)
-        for i in range(depth - 2):
-            add_conv(min_features, min_features, True, bool(i))
-        if depth > 1:
-            add_conv(min_features, out_features, True, bool(depth - 2))
-
     def forward(self, function_input, pre_activated=False):
-        out = self.layers[0](function_input, pre_activated=pre_activated)
-        for layer in self.layers[1:]:
+        first, *rest = self.layers
+        out = first(function_input, pre_activated=pre_activated)
+        for layer in rest:
             out = layer(out)
         return out
 
@@ -371,78 +372,76 @@ class LinearModule(nn.Module):
 
 
 class Block(nn.Module):
+    """One up / down stage (libs/block.py:15-52): a gated conv branch over the resampled skip branch and, on attention
+    stages, a channel gate and a position gate on the result.  Gate k of the stage takes style scale k."""
+
     def __init__(self, in_size, in_features, out_features, stride, transpose, block_number, cat_out=True, dim=2, cfg=None):
         super().__init__()
         cfg = cfg or get_default()
         self.scale_layer = Scale(in_features, out_features, stride, transpose, dim=dim)
-        self.res_module_i = ResModule(_identity, Norm(in_features, DeepResidualConv(in_features, out_features, transpose, stride,
-                                                                                   depth=cfg.depth, dim=dim, cfg=cfg), dim=dim),
-                                      m=3)
-        self.attention = bool(in_size >= cfg.min_attention_size and block_number % cfg.attention_every_nth_layer == 0)
+        conv = DeepResidualConv(in_features, out_features, transpose, stride, depth=cfg.depth, dim=dim, cfg=cfg)
+        self.res_module_i = ResModule(_identity, Norm(in_features, conv, dim=dim), m=3)
+        self.attention = arch.stage_has_attention(in_size, block_number, cfg)
+        self._gates = []
         if self.attention:
             self.res_module_f = ResModule(_identity, Norm(out_features, feature_attention(in_size, out_features, dim=dim, cfg=cfg),
                                                           dim=dim))
             self.res_module_s = ResModule(_identity, Norm(out_features, SelfAttention(out_features), dim=dim))
+            self._gates = [self.res_module_f, self.res_module_s]
         self.cat_out = cat_out
 
     def forward(self, function_input, scales=None):
-        if scales is None:
-            scales = [None] * 4
-        scaled = self.scale_layer(function_input)
-        out = self.res_module_i(scaled, function_input, scales[0])
-        if self.attention:
-            out = self.res_module_f(out, scale=scales[1])
-            out = self.res_module_s(out, scale=scales[2])
+        scales = list(scales) if scales is not None else []
+        scales += [None] * (1 + len(self._gates) - len(scales))
+        out = self.res_module_i(self.scale_layer(function_input), function_input, scales[0])
+        for gate, scale in zip(self._gates, scales[1:]):
+            out = gate(out, scale=scale)
         return out
 
 
 class BlockBlock(nn.Module):
+    """A stack of Blocks and - in the generator (`mul_channel`) - the style chain that feeds their norms (libs/block.py:55-127).
+    The stack is described first (`arch.stack_plan`: one `Stage` per block, with the (in, out) widths of its style linears);
+    all blocks are built before any style linear, which fixes the RNG draw order."""
+
     def __init__(self, block_count, in_size, features, strides, transpose, mul_channel=False, dim=2, cfg=None):
         super().__init__()
         cfg = cfg or get_default()
         self.block_count = block_count
-        z = cfg.input_vector_z
-        size = float(in_size)
-        blocks = []
-        for i in range(block_count):
-            size = size * strides[i] if transpose else size / strides[i]
-            blocks.append(Block(int(size + 1 - 1e-12), features[i], features[i + 1], strides[i], transpose, i, dim=dim, cfg=cfg))
-        self.blocks = blocks
-        for i, block in enumerate(blocks):
-            setattr(self, "block_%d" % i, block)
-        sums, depths = [0], []
-        if mul_channel:
-            mul_blocks = []
-            prev_out = 0
-            for i in range(block_count):
-                extra = 2 * int(blocks[i].attention)
-                depths.append(1 + extra)
-                sums.append(sums[-1] + extra + 1)
-                inp, out = features[i], features[i + 1]
-                group_inp = prev_out if (prev_out and prev_out != inp) else inp
-                mul_blocks.append(LinearModule(group_inp + z * bool(i), inp))
-                if extra:
-                    mul_blocks.append(LinearModule(inp + z, out))
-                    mul_blocks.extend(LinearModule(out + z, out) for _ in range(1, extra))
-                    prev_out = out
-                else:
-                    prev_out = inp
-            self.mul_blocks = mul_blocks
-            for i, block in enumerate(mul_blocks):
-                setattr(self, "mul_block_%d" % i, block)
-        self.depths = depths
-        self.sums = sums
+        self.plan = arch.stack_plan(block_count, in_size, features, strides, transpose, mul_channel, cfg)
+        self.blocks = []
+        for st in self.plan:
+            block = Block(st.side, st.cin, st.cout, st.stride, transpose, st.index, dim=dim, cfg=cfg)
+            setattr(self, "block_%d" % st.index, block)
+            self.blocks.append(block)
+        # style chain: flat list of linears, `first_style[i]` = position of stage i's first one
+        self.mul_blocks = []
+        self.first_style = []
+        for st in self.plan:
+            self.first_style.append(len(self.mul_blocks))
+            for fan_in, fan_out in st.style:
+                linear = LinearModule(fan_in, fan_out)
+                setattr(self, "mul_block_%d" % len(self.mul_blocks), linear)
+                self.mul_blocks.append(linear)
+        self.depths = [len(st.style) for st in self.plan] if mul_channel else []
+        self.sums = self.first_style + [len(self.mul_blocks)] if mul_channel else [0]
         self.out_features = features[block_count]
 
+    def _style_scales(self, stage, latent, carry):
+        """Runs stage `stage`'s style linears: each sees [latent, previous activated output] and yields (a) its RootTanh
+        output - the next link's carry - and (b) its pre-activation as a [B, C, 1, 1] norm scale."""
+        scales = []
+        start = self.first_style[stage]
+        for linear in self.mul_blocks[start:start + len(self.plan[stage].style)]:
+            carry, pre = linear(latent if carry is None else ops.cat_channels(latent, carry))
+            scales.append(pre.view(*pre.shape, 1, 1))
+        return scales, carry
+
     def forward(self, function_input, noise=None):
-        chain = None
-        for i in range(self.block_count):
-            operand = None
+        out, carry = function_input, None
+        for stage, block in enumerate(self.blocks):
+            scales = None
             if noise is not None:
-                operand = []
-                for idx in range(self.depths[i]):
-                    chain = noise if chain is None else ops.cat_channels(noise, chain)
-                    chain, factor = self.mul_blocks[self.sums[i] + idx](chain)
-                    operand.append(factor.view(*factor.size(), 1, 1))
-            function_input = self.blocks[i](function_input, scales=operand)
-        return function_input
+                scales, carry = self._style_scales(stage, noise, carry)
+            out = block(out, scales=scales)
+        return out

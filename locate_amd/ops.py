@@ -84,22 +84,168 @@ tanh = TanhFn.apply
 # ------------------------------------------------------------------------------------------------
 # InPlaceNorm
 # ------------------------------------------------------------------------------------------------
-class stacked_calls:
-    """Context: the batch of every op inside stacks `n` independent forward calls of the network (the reference runs
-    them one after the other, main.py:149-152).  Ops whose result depends on the whole batch - InPlaceNorm's global
-    statistics - then treat each of the n equal slices on its own."""
-    current = 1
+class Runtime:
+    """Host-side state of ONE network's forward / backward passes: how many independent calls the current forward stacks
+    along the batch, the side stream its weight gradients go to, and what its running backward pass has deferred to its
+    end (spectral-norm dv, side-stream results).  Every network owns one (`Generator.runtime`, `Discriminator.runtime`;
+    its InPlaceNorm / SpectralNorm layers point at it), so two networks - or two models of the same class - in one process
+    never see each other's state; layers built on their own share `DEFAULT_RUNTIME`.  The C ABI below this layer is
+    stateless; this object is the Python layer's only mutable state besides the tensors themselves.
 
-    def __init__(self, n):
-        self.n = int(n)
+    Not supported (nor by the reference): two backward passes of the SAME network at the same time - they would race on
+    its `.grad` buffers anyway."""
+
+    def __init__(self):
+        self.stacked = 1                 # forward: the batch holds this many independent calls (main.py:149-152 as one pass)
+        self.weight_grad_stream = None   # backward: weight gradients are launched on this stream (None: in line)
+        self._dv_layers = {}             # id(v) -> (v, u, w, h, wd, state): layers whose dv is still to be finalised
+        self._dv_tables = {}             # tuple of addresses -> (device table, max_h, max_wd)
+        self._end_scheduled = False
+        self._side = None                # side stream with work of the running backward pass on it
+        self._side_results = []          # (parameter, gradient produced on the side stream)
+        self._keep = []                  # operands of side-stream kernels: alive until the join
+
+    # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
+    def __deepcopy__(self, memo):
+        return Runtime()
+
+    def stacked_calls(self, n):
+        return _Stacked(self, n)
+
+    def weight_grads_on(self, stream):
+        return _OnStream(self, stream)
+
+    def reset(self):
+        """Forget whatever an aborted backward pass left behind (an exception inside the autograd engine never runs its
+        callbacks); the step driver calls this before every backward()."""
+        self._end_scheduled = False
+        self._side = None
+        self._side_results = []
+        self._keep = []
+        for entry in self._dv_layers.values():
+            entry[5]["k"] = 0
+        self._dv_layers = {}
+
+    # ---- end-of-backward work ----------------------------------------------------------------------------------------
+    def _schedule_end(self):
+        if not self._end_scheduled:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self._end_scheduled = True
+
+    def _end_of_backward(self):
+        self._end_scheduled = False
+        side, self._side = self._side, None
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            results, self._side_results = self._side_results, []
+            self._keep = []
+            for param, grad in results:
+                if param.grad is None:
+                    param.grad = grad
+                else:
+                    param.grad.add_(grad)
+        self._finalize_dv()
+
+    def defer_dv(self, v_param, u_param, w, h, wd):
+        """Registers a layer for the batched dv of this backward pass; returns the slot its dsigma goes to."""
+        st = v_param.__dict__.get("_locate_dv")
+        if st is None or st["dv"].device != v_param.device:
+            nch = (h + 63) // 64
+            st = {"dv": torch.empty_like(v_param.detach()), "dsig": torch.zeros(4, dtype=torch.float32, device=v_param.device),
+                  "scratch": torch.empty(wd + h + nch * wd, dtype=torch.float32, device=v_param.device), "k": 0}
+            v_param.__dict__["_locate_dv"] = st
+        k = st["k"]
+        if k >= 4:
+            raise RuntimeError("a spectral-norm layer was differentiated through more than 4 forwards in one backward pass")
+        st["k"] = k + 1
+        self._dv_layers[id(v_param)] = (v_param, u_param, w, h, wd, st)
+        self._schedule_end()
+        return st["dsig"][k:]
+
+    def _finalize_dv(self):
+        import struct
+        layers = list(self._dv_layers.values())
+        self._dv_layers = {}
+        if not layers:
+            return
+        key = tuple((w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["scratch"].data_ptr()) for _, u, w, _, _, st in layers)
+        tab = self._dv_tables.get(key)
+        if tab is None:
+            rec = struct.Struct("<8Q4i")
+            buf = bytearray()
+            for v, u, w, h, wd, st in layers:
+                base = st["scratch"].data_ptr()
+                buf += rec.pack(w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["dsig"].data_ptr(), 0, base, base + 4 * wd,
+                                base + 4 * (wd + h), h, wd, (h + 63) // 64, 0)
+            host = torch.frombuffer(buf, dtype=torch.uint8).clone()
+            # the table holds raw addresses only (no tensor references): the layers' own parameters keep the memory alive
+            tab = (host.to(layers[0][0].device), max(l[3] for l in layers), max(l[4] for l in layers))
+            if len(self._dv_tables) > 8:
+                self._dv_tables.clear()
+            self._dv_tables[key] = tab
+        check(lib().locate_sn_dv_batched(tab[0].data_ptr(), len(layers), tab[1], tab[2], _stream()), "locate_sn_dv_batched")
+        for v, u, w, h, wd, st in layers:
+            st["k"] = 0
+            if v.grad is None or v.grad is st["dv"]:
+                v.grad = st["dv"]
+            else:
+                v.grad.add_(st["dv"])
+
+
+class _Stacked:
+    """with runtime.stacked_calls(n): the batch of every op inside stacks `n` independent forward calls of the network (the
+    reference runs them one after the other, main.py:149-152).  Ops whose result depends on the whole batch - InPlaceNorm's
+    global statistics - then treat each of the n equal slices on its own."""
+
+    def __init__(self, rt, n):
+        self.rt, self.n = rt, int(n)
 
     def __enter__(self):
-        self.prev = stacked_calls.current
-        stacked_calls.current = self.n
+        self.prev = self.rt.stacked
+        self.rt.stacked = self.n
 
     def __exit__(self, *exc):
-        stacked_calls.current = self.prev
+        self.rt.stacked = self.prev
         return False
+
+
+class _OnStream:
+    """with runtime.weight_grads_on(stream): during backward(), the weight gradients of the spectral-normalised contractions
+    (and their spectral-norm backward) are launched on `stream` instead of the stream of the backward pass.  They sit
+    beside the pass's critical path - the chain of input gradients - and most kernels of that chain are too small to fill
+    the chip, so the two run concurrently.  The results are NOT returned through autograd (a consumer on the main stream
+    could read them too early): they are assigned to / accumulated into `.grad` of the weight, u and v parameters by a
+    callback at the end of the backward pass, after the main stream has joined the side stream.  Consequences: only for
+    `.backward()` (torch.autograd.grad would see no weight gradients), and tensor hooks on those parameters do not fire."""
+
+    def __init__(self, rt, stream):
+        self.rt, self.stream = rt, stream
+
+    def __enter__(self):
+        self.prev = self.rt.weight_grad_stream
+        self.rt.weight_grad_stream = self.stream
+
+    def __exit__(self, *exc):
+        self.rt.weight_grad_stream = self.prev
+        return False
+
+
+DEFAULT_RUNTIME = Runtime()     # layers used on their own (not inside a Generator / Discriminator)
+
+
+def stacked_calls(n):
+    """Stacked-call context of the default runtime (stand-alone layers)."""
+    return DEFAULT_RUNTIME.stacked_calls(n)
+
+
+def weight_grad_stream(stream):
+    """Side-stream context of the default runtime (stand-alone layers)."""
+    return DEFAULT_RUNTIME.weight_grads_on(stream)
+
+
+def reset_backward_state(*runtimes):
+    for rt in runtimes or (DEFAULT_RUNTIME,):
+        rt.reset()
 
 
 class InPlaceNormFn(torch.autograd.Function):
@@ -107,11 +253,10 @@ class InPlaceNormFn(torch.autograd.Function):
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
-    def forward(ctx, x, scale, bias, with_act):
+    def forward(ctx, x, scale, bias, with_act, groups):
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
-        groups = stacked_calls.current
         if B % groups:
             raise ValueError("norm: batch %d does not split into %d stacked calls" % (B, groups))
         per_sample = scale.numel() == B * C and (B > 1 and scale.shape[0] == B)
@@ -144,11 +289,11 @@ class InPlaceNormFn(torch.autograd.Function):
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
                                 _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), st), "locate_norm_bwd")
-        return dx, dscale, dbias, None
+        return dx, dscale, dbias, None, None
 
 
-def inplace_norm(x, scale, bias, with_act=False):
-    return InPlaceNormFn.apply(x, scale, bias, with_act)
+def inplace_norm(x, scale, bias, with_act=False, runtime=None):
+    return InPlaceNormFn.apply(x, scale, bias, with_act, (runtime or DEFAULT_RUNTIME).stacked)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -412,125 +557,12 @@ def _panel(owner, w, geom, garr, adjoint):
 
 
 # ------------------------------------------------------------------------------------------------
-# gradient of the spectral-norm v vectors, batched per backward pass
+# gradient of the spectral-norm v vectors, batched per backward pass (Runtime.defer_dv / _finalize_dv)
 #   dv = (sum_k dsigma_k) * W^T u_latest  - the same W^T u for every graph that used the layer, so it is computed
 #   once per layer and pass, for all layers in three launches, from a callback at the end of the backward pass
 #   (instead of three launches per layer and graph).  The result is written to a persistent buffer that becomes
 #   v.grad (accumulated into an existing foreign .grad).
 # ------------------------------------------------------------------------------------------------
-class _PendingDV:
-    layers = {}          # id(v) -> (v, u, w, h, wd, state)
-    tables = {}          # tuple(ids) -> (device table, max_h, max_wd, keep-alive)
-
-
-class weight_grad_stream:
-    """Context for backward(): weight gradients of the spectral-normalised contractions (and their spectral-norm
-    backward) are launched on `stream` instead of the stream of the backward pass.  They sit beside the pass's critical
-    path - the chain of input gradients - and most kernels of that chain are too small to fill the chip, so the two run
-    concurrently.  The results are NOT returned through autograd (a consumer on the main stream could read them too
-    early): they are assigned to / accumulated into `.grad` of the weight, u and v parameters by a callback at the end of
-    the backward pass, after the main stream has joined the side stream.  Consequences: only for `.backward()`
-    (torch.autograd.grad would see no weight gradients), and tensor hooks on those parameters do not fire."""
-    current = None
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self.prev = weight_grad_stream.current
-        weight_grad_stream.current = self.stream
-
-    def __exit__(self, *exc):
-        weight_grad_stream.current = self.prev
-        return False
-
-
-class _BackwardEnd:
-    scheduled = False
-    side = None          # side stream with work of this backward pass on it
-    pending = []         # (parameter, gradient tensor produced on the side stream)
-    keep = []            # operands of the side-stream kernels: alive until the join, so their memory is not recycled under them
-
-
-def reset_backward_state():
-    """Forget whatever an aborted backward pass (an exception inside the autograd engine never runs its callbacks) left
-    behind; the step driver calls this before every backward()."""
-    _BackwardEnd.scheduled = False
-    _BackwardEnd.side = None
-    _BackwardEnd.pending = []
-    _BackwardEnd.keep = []
-    for entry in _PendingDV.layers.values():
-        entry[5]["k"] = 0
-    _PendingDV.layers = {}
-
-
-def _schedule_backward_end():
-    if not _BackwardEnd.scheduled:
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        _BackwardEnd.scheduled = True
-
-
-def _end_of_backward():
-    _BackwardEnd.scheduled = False
-    side, _BackwardEnd.side = _BackwardEnd.side, None
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-        pending, _BackwardEnd.pending = _BackwardEnd.pending, []
-        _BackwardEnd.keep = []
-        for param, grad in pending:
-            if param.grad is None:
-                param.grad = grad
-            else:
-                param.grad.add_(grad)
-    _finalize_pending_dv()
-
-
-def _register_pending_dv(v_param, u_param, w, h, wd):
-    st = v_param.__dict__.get("_locate_dv")
-    if st is None or st["dv"].device != v_param.device:
-        nch = (h + 63) // 64
-        st = {"dv": torch.empty_like(v_param.detach()), "dsig": torch.zeros(4, dtype=torch.float32, device=v_param.device),
-              "scratch": torch.empty(wd + h + nch * wd, dtype=torch.float32, device=v_param.device), "k": 0}
-        v_param.__dict__["_locate_dv"] = st
-    k = st["k"]
-    if k >= 4:
-        raise RuntimeError("a spectral-norm layer was differentiated through more than 4 forwards in one backward pass")
-    st["k"] = k + 1
-    _PendingDV.layers[id(v_param)] = (v_param, u_param, w, h, wd, st)
-    _schedule_backward_end()
-    return st["dsig"][k:]
-
-
-def _finalize_pending_dv():
-    import struct
-    layers = list(_PendingDV.layers.values())
-    _PendingDV.layers = {}
-    if not layers:
-        return
-    key = tuple((id(v), w.data_ptr(), u.data_ptr()) for v, u, w, _, _, _ in layers)
-    tab = _PendingDV.tables.get(key)
-    if tab is None:
-        rec = struct.Struct("<8Q4i")
-        buf = bytearray()
-        for v, u, w, h, wd, st in layers:
-            base = st["scratch"].data_ptr()
-            buf += rec.pack(w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["dsig"].data_ptr(), 0, base, base + 4 * wd,
-                            base + 4 * (wd + h), h, wd, (h + 63) // 64, 0)
-        host = torch.frombuffer(buf, dtype=torch.uint8).clone()
-        dev_tab = host.to(layers[0][0].device)
-        tab = (dev_tab, max(l[3] for l in layers), max(l[4] for l in layers), [l[2] for l in layers])
-        if len(_PendingDV.tables) > 8:
-            _PendingDV.tables.clear()
-        _PendingDV.tables[key] = tab
-    check(lib().locate_sn_dv_batched(tab[0].data_ptr(), len(layers), tab[1], tab[2], _stream()), "locate_sn_dv_batched")
-    for v, u, w, h, wd, st in layers:
-        st["k"] = 0
-        if v.grad is None or v.grad is st["dv"]:
-            v.grad = st["dv"]
-        else:
-            v.grad.add_(st["dv"])
-
-
 class _PackPlans:
     cache = {}       # signature of the stale set -> (device job table, n_jobs, total_blocks)
 
@@ -670,9 +702,9 @@ def _weight_grad_partials(spec, geom, garr):
     return L.locate_groupdot_wgrad_partials(geom[1], geom[2])
 
 
-def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v):
+def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v):
     """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
-    (_register_pending_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side)."""
+    (Runtime.defer_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side)."""
     L = lib()
     st = _stream()
     groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
@@ -686,7 +718,7 @@ def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
         _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None)
-        dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
+        dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
         gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
         Bn, Mn = gy.shape[0], gy.shape[1]
         check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bias), groups, Bn // groups, Mn,
@@ -699,7 +731,7 @@ def _conv_weight_grad(x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom
     npart = _weight_grad_partials(spec, geom, garr)
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
     _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial)
-    dsig = _register_pending_dv(v_param, u_param, w, h, wd) if need_v else None
+    dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
     check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
           "locate_sn_weight_bwd")
     return gw, gu
@@ -728,7 +760,7 @@ class SNConvFn(torch.autograd.Function):
     left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None):
         x = _dense(x, "conv input")
         w = _c(w_bar, "weight_bar")
         owner = _panel_owner(w_bar)
@@ -744,6 +776,7 @@ class SNConvFn(torch.autograd.Function):
             ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.owner = owner
+        ctx.rt = rt or DEFAULT_RUNTIME
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
         return y
 
@@ -761,32 +794,33 @@ class SNConvFn(torch.autograd.Function):
         if need_x:
             gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma)
         if need_w or need_u or need_v:
-            side = weight_grad_stream.current
+            rt = ctx.rt
+            side = rt.weight_grad_stream
             if side is None:
-                gw, gu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                gw, gu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
                 if not need_w:
                     gw = None
             else:
                 side.wait_stream(torch.cuda.current_stream())        # gy (and x) are complete on the pass's stream
                 with torch.cuda.stream(side):
-                    sgw, sgu = _conv_weight_grad(x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
-                _BackwardEnd.side = side
-                _BackwardEnd.keep.append((x, gy, y, bsaved, w, sigma, wv))
+                    sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                rt._side = side
+                rt._keep.append((x, gy, y, bsaved, w, sigma, wv))
                 if need_w:
-                    _BackwardEnd.pending.append((ctx.owner, sgw.view(ctx.owner.shape)))
+                    rt._side_results.append((ctx.owner, sgw.view(ctx.owner.shape)))
                 if need_u:
-                    _BackwardEnd.pending.append((ctx.u, sgu))
-                _schedule_backward_end()
+                    rt._side_results.append((ctx.u, sgu))
+                rt._schedule_end()
         if ctx.has_bias and need_b:
             gb = _bias_grad(gy)
-        # gv is assigned to v.grad by _finalize_pending_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None
+        # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass
+        return gx, gw, gu, None, gb, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
     batched update is supplied."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime)

@@ -29,7 +29,7 @@ def broadcast_module_state(module, src=0, extra_tensors=()):
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None):
         """`late`: predicate (or collection) of parameters whose .grad is only assigned at the very end of the backward
-        pass, outside autograd's accumulation (the spectral-norm v vectors, ops._finalize_pending_dv).  They get buckets
+        pass, outside autograd's accumulation (the spectral-norm v vectors, ops.Runtime._finalize_dv).  They get buckets
         of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients."""
         self.params = [p for p in params]
         if late is None:

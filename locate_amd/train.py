@@ -47,7 +47,7 @@ class TrainStep:
                  concurrent_d=False, stacked_d=None, overlap_wgrad=False):
         self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
         # overlap_wgrad: the weight gradients of a backward pass run on a second stream beside its chain of input gradients
-        # (ops.weight_grad_stream); same values, the parameters' .grad are complete when backward() returns.  Off by
+        # (ops.Runtime.weight_grads_on); same values, the parameters' .grad are complete when backward() returns.  Off by
         # default: measured neutral under hipGraph replay (12.76 vs 12.74 ms at config 2 - the fork/join branches of one
         # captured graph do not run side by side) and slower eagerly (more host work per layer)
         self.overlap_wgrad = bool(overlap_wgrad)
@@ -70,12 +70,13 @@ class TrainStep:
 
     def _backward(self, outputs, grads):
         from . import ops
-        ops.reset_backward_state()
+        runtimes = [getattr(net, "runtime", ops.DEFAULT_RUNTIME) for net in (self.gen, self.dis)]
+        ops.reset_backward_state(*runtimes)
         if not self.overlap_wgrad:
             return torch.autograd.backward(outputs, grads)
         if self._wgrad_side is None:
             self._wgrad_side = torch.cuda.Stream()
-        with ops.weight_grad_stream(self._wgrad_side):
+        with runtimes[0].weight_grads_on(self._wgrad_side), runtimes[1].weight_grads_on(self._wgrad_side):
             return torch.autograd.backward(outputs, grads)
 
     # ---- the four phases of one iteration (kept separate so that each can be its own hipGraph) --------------

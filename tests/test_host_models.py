@@ -229,3 +229,54 @@ def test_nadam_state_dict_roundtrip_keeps_the_schedule_in_float64(tmp_path):
         a, b = opt.state[p], opt2.state[q]
         assert b["sched"].dtype == torch.float64 and torch.equal(a["sched"], b["sched"])
         assert torch.equal(a["exp_avg"], b["exp_avg"])
+
+
+def test_architecture_descriptions_match_the_survey_tables():
+    """locate_amd.arch against SURVEY.md Appendix A / section 8(a) a11 (measured on the reference): attention stages, style
+    chain layout (`depths [1,1,3,1,3]`, `sums [0,1,2,5,6,9]` at 64x64; ten linears at 128x128) and its widths."""
+    from locate_amd import arch
+    cfg = NetConfig(64)
+    feats = arch.generator_widths(cfg)
+    plan = arch.stack_plan(5, 2, feats, [2] * 5, True, True, cfg)
+    assert [st.side for st in plan] == [4, 8, 16, 32, 64]
+    assert [st.attention for st in plan] == [False, False, True, False, True]
+    assert [len(st.style) for st in plan] == [1, 1, 3, 1, 3]
+    flat = [w for st in plan for w in st.style]
+    assert flat[:4] == [(64, 64), (128, 768), (832, 384), (448, 192)]
+    assert flat[4:] == [(256, 192), (256, 192), (256, 96), (160, 48), (112, 48)]
+    G = Generator(cfg)
+    assert G.conv_block.depths == [1, 1, 3, 1, 3] and G.conv_block.sums == [0, 1, 2, 5, 6, 9]
+    assert sum(len(st.style) for st in arch.stack_plan(6, 2, arch.generator_widths(NetConfig(128)), [2] * 6, True, True,
+                                                        NetConfig(128))) == 10
+    dplan = arch.stack_plan(5, 32, arch.discriminator_widths(cfg), [2] * 5, False, False, cfg)
+    assert [st.side for st in dplan] == [16, 8, 4, 2, 1] and [st.attention for st in dplan] == [True, False, False, False, False]
+    assert all(st.style == () for st in dplan)
+    # conv chains: kernels / pads of the three stage kinds, and the DEPTH > 1 layout
+    assert arch.conv_chain(64, 64, True, 2, True, 1, cfg) == [arch.ConvLink(64, 64, 4, 2, 1, True, False, False)]
+    assert arch.conv_chain(32, 64, False, 2, True, 1, cfg)[0][2:5] == (5, 2, 2)
+    assert arch.conv_chain(48, 3, False, 1, False, 1, cfg)[0][2:5] == (3, 1, 1)
+    chain = arch.conv_chain(32, 32, False, 2, True, 3, cfg)
+    assert [(l.cin, l.cout, l.normalized, l.residual) for l in chain] == [(32, 8, False, False), (8, 8, False, True), (8, 32, True, False)]
+    assert [c[:4] for c in arch.squeeze_plan(16, 192, cfg)] == [(192, 48, (16, 1), 1), (48, 48, (1, 16), 1), (48, 192, (1, 1), 1)]
+
+
+def test_networks_do_not_share_runtime_state():
+    """Every network owns its ops.Runtime; stacking calls in one discriminator is invisible to another model's layers
+    (the class-level state of round 1 is gone), and a deep copy gets a fresh runtime shared by all of ITS layers."""
+    import copy
+    from locate_amd import ops
+    from locate_amd.nn import InPlaceNorm, SpectralNorm
+    cfg = NetConfig(image_size=32, base_feature_factor=1)
+    D1, D2, G = Discriminator(cfg), Discriminator(cfg), Generator(cfg)
+    rts = {id(D1.runtime), id(D2.runtime), id(G.runtime), id(ops.DEFAULT_RUNTIME)}
+    assert len(rts) == 4
+    for net in (D1, D2, G):
+        bound = [m for m in net.modules() if isinstance(m, (InPlaceNorm, SpectralNorm))]
+        assert bound and all(m.runtime is net.runtime for m in bound)
+    with D1.runtime.stacked_calls(3):
+        assert D1.runtime.stacked == 3 and D2.runtime.stacked == 1 and ops.DEFAULT_RUNTIME.stacked == 1
+    assert D1.runtime.stacked == 1
+    D3 = copy.deepcopy(D1)
+    assert D3.runtime is not D1.runtime
+    assert all(m.runtime is D3.runtime for m in D3.modules() if isinstance(m, (InPlaceNorm, SpectralNorm)))
+    assert SpectralNorm(torch.nn.Conv2d(3, 4, 1)).runtime is None            # stand-alone layer: the default runtime at call time
