@@ -123,15 +123,20 @@ int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* pa
                          int* blocks_out);
 int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
+/* arrival counters for split-K launches that combine their partial tiles INSIDE the launch (the tile's last-arriving block
+ * sums them in a fixed order: bit-reproducible): locate_conv_counter_bytes() bytes of device memory, zero before their first
+ * use, left zero by every completed call, never shared by launches that may run concurrently (one block per layer and
+ * direction is what the Python layer keeps).  `counters` may be NULL: a second kernel then sums the partial tiles. */
+size_t locate_conv_counter_bytes(void);
 /* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride] */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                     int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
-                    void* stream);
+                    void* counters, void* stream);
 /* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                       int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
-                      void* stream);
+                      void* counters, void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.

@@ -337,9 +337,11 @@ struct IgParams {
     int B, C, H, W;      // gathered tensor: C = reduction channels
     int M, OH, OW;       // produced tensor
     int istride, ostep, nphase;
-    int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab` (dense [ksplit][B, M, OH, OW])
-    float* slab;
+    int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab`
+    float* slab;         //   combine == 0: dense [ksplit][B, M, OH, OW], summed by igemm_slab_reduce_kernel
     long long slab_stride;
+    int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
+    unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
     IgPhase ph[4];
 };
 
@@ -362,11 +364,10 @@ __device__ __forceinline__ void igemm_col_scales(const IgParams& p, const IgPhas
 template <int WGM, int WGN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN],
                                                const float (&col_scale)[TN], int N, int n0, int m0, int zsplit, int wm,
-                                               int wn, int lane, float* stage) {
+                                               int wn, int lane, float* stage, bool split) {
     const int lrow = lane >> 5, lcol = lane & 31;
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const long long plane = (long long)p.OH * p.OW;
-    const bool split = p.ksplit > 1;
     // Small output planes (linears and the deep layers: 1x1 ... 4x4 maps): the lanes of an accumulator register hold 32
     // different columns n = (b, pixel), whose addresses are a whole channel stack apart - 64 scattered 4-byte stores per
     // instruction (measured: 5-11 us of a 10 us launch).  There the 32x32 tile goes through a wave-private LDS patch and
@@ -508,6 +509,7 @@ __device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsig
 }
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
@@ -634,7 +636,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane, nullptr);
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane, nullptr, p.ksplit > 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -796,8 +798,79 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         __syncthreads();
     }
     // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
-    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, zsplit, wm, wn, lane,
-                                     reinterpret_cast<float*>(&Bs[0][0][0][0]) + wid * (32 * 33));   // Bs: 24 KiB for every tile shape
+    float* const stage = reinterpret_cast<float*>(&Bs[0][0][0][0]) + wid * (32 * 33);   // Bs: 24 KiB for every tile shape
+    bool combined = false;
+    if (p.ksplit > 1 && p.combine) {
+        // ---- split-K combined inside the launch (no reduction kernel, no slab in the output's layout) ----
+        // Every block of a tile stores its partial accumulators as they sit in its registers - thread t, fragment f at
+        // [z][tile][f][t][4]: one contiguous KiB per store instruction - write-through (sc1), drains them, and one lane
+        // takes a ticket from the tile's counter.  The block that draws the last ticket sums all ksplit partials IN z
+        // ORDER (its own included, re-read: the result does not depend on which block came last - bit-reproducible),
+        // and runs the ordinary epilogue.  Protocol (cdna_hip_programming.md, Guideline 16, counter form): sc1 payload
+        // stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one relaxed agent-scope fetch_add;
+        // last arriver: agent-scope acquire -> s_waitcnt vmcnt(0) -> barrier -> sc1 loads.  The counter is reset by the last
+        // arriver, so the counter block stays zero between launches (it must be zero before its first use).
+        constexpr int FR = TM * TN * 4;                                   // 16-byte fragments per thread
+        const int tile = (zphase * (int)gridDim.y + by) * (int)gridDim.x + bx;
+        const int ntiles = p.nphase * (int)gridDim.y * (int)gridDim.x;
+        const unsigned tile_bytes = FR * 256 * 16;
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)((unsigned)p.ksplit * ntiles * tile_bytes), 0x00020000);
+        const unsigned my = ((unsigned)(zsplit * ntiles + tile)) * tile_bytes + (unsigned)tid * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x4 v;
+                    v[0] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 0]); v[1] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 1]);
+                    v[2] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 2]); v[3] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, (int)(my + (unsigned)(((i * TN + j) * 4 + q) * 256 * 16)), 0, 16);   // aux 16 = sc1
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const flag = reinterpret_cast<unsigned*>(&Bs[0][0][0][0]) + 6000;     // beyond the four 32 x 33 patches
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = ticket == (unsigned)(p.ksplit - 1);
+            if (last) {
+                __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        const unsigned t0 = (unsigned)tile * tile_bytes + (unsigned)tid * 16u;
+        const unsigned zstride = (unsigned)ntiles * tile_bytes;
+        // the accumulators (stored above) become the sum; one z at a time, its fragments in two batches of loads in flight
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        constexpr int HB = 4;
+        for (int z = 0; z < p.ksplit; ++z) {
+            const unsigned zb = t0 + (unsigned)z * zstride;
+#pragma unroll
+            for (int h0 = 0; h0 < FR; h0 += HB) {
+                u32x4 v[HB];
+#pragma unroll
+                for (int f = 0; f < HB; ++f) v[f] = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(zb + (unsigned)((h0 + f) * 256 * 16)), 0, 16);
+#pragma unroll
+                for (int f = 0; f < HB; ++f) {
+                    const int g = h0 + f, i = g / (TN * 4), j = (g / 4) % TN, q = g % 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += __builtin_bit_cast(float, v[f][e]);
+                }
+            }
+        }
+        __syncthreads();      // the flag word's patch neighbours are about to be reused by the staged epilogue
+        combined = true;
+    }
+    igemm_epilogue<WGM, WGN, TM, TN>(p, ph, acc, col_scale, N, n0, m0, combined ? 0 : zsplit, wm, wn, lane, stage, p.ksplit > 1 && !combined);
 }
 
 // out[b, m, :] = bias[m] + scale * sum_z slab[z][b, m, :]
@@ -951,7 +1024,39 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     return want < 1 ? 1 : (int)want;
 }
 
-static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, const char* who) {
+// How one launch splits K: the split count, whether the partial tiles are combined inside the launch (see the kernel) or by
+// igemm_slab_reduce_kernel, and the slab space either way.  In-launch combining reads ksplit x tile bytes serially in the
+// tile's last block, so it is taken only while that stays small (<= 512 KiB: ~5 us) and the tile count fits the counter
+// block; deep splits of tiny outputs (the style linears, the discriminator's 1x1 ... 4x4 tail) keep the reduction kernel,
+// which spreads the same bytes over the whole chip.
+#define IG_MAX_COUNTERS 1024
+struct SplitPlan {
+    int ksplit, combine, gx, gy;
+    size_t slab_floats;
+};
+
+static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counters) {
+    SplitPlan sp;
+    const int bm = pick_bm(p.M);
+    int min_kpad = 1 << 30;
+    for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
+    int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
+    if (ks > min_kpad / IG_BK) ks = min_kpad / IG_BK;
+    if (ks < 1) ks = 1;
+    sp.ksplit = ks;
+    sp.gx = (nmax + 127) / 128;
+    sp.gy = (p.M + bm - 1) / bm;
+    const long long ntiles = (long long)sp.gx * sp.gy * p.nphase;
+    const long long tile_floats = (long long)bm * 128;
+    const long long legacy = ks > 1 ? (long long)ks * p.B * p.M * p.OH * p.OW : 0;
+    const long long fused = ks > 1 ? (long long)ks * ntiles * tile_floats : 0;
+    sp.combine = have_counters && ks > 1 && (long long)ks * tile_floats * 4 <= (512 << 10) && ntiles <= IG_MAX_COUNTERS &&
+                 fused * 4 < (1ll << 31) && !path_disabled("bx6") && !path_disabled("combine");
+    sp.slab_floats = (size_t)(sp.combine ? fused : legacy);
+    return sp;
+}
+
+static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who) {
     if (pointwise_ok(p)) {
         p.ksplit = 1;
         launch_pointwise(p, st);
@@ -959,14 +1064,13 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
         return LOCATE_OK;
     }
     const int bm = pick_bm(p.M);
-    int min_kpad = 1 << 30;
-    for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
-    p.ksplit = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
+    const SplitPlan sp = igemm_split_plan(p, nmax, counters != nullptr);
+    p.ksplit = sp.ksplit;
+    p.combine = sp.combine;
+    p.counters = counters;
     p.slab = static_cast<float*>(slab_ws);
     p.slab_stride = (long long)p.B * p.M * p.OH * p.OW;
-    if (p.ksplit > min_kpad / IG_BK) p.ksplit = min_kpad / IG_BK;
-    if (p.ksplit < 1) p.ksplit = 1;
-    dim3 grid((nmax + 127) / 128, (p.M + bm - 1) / bm, p.nphase * p.ksplit);
+    dim3 grid(sp.gx, sp.gy, p.nphase * p.ksplit);
     for (int i = 0; i < p.nphase; ++i)
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
     if (!path_disabled("bx6")) {
@@ -981,7 +1085,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, hipStream_t st, co
         else conv_igemm_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     }
     LOCATE_LAUNCH_CHECK(who);
-    if (p.ksplit > 1) {
+    if (p.ksplit > 1 && !p.combine) {
         const long long total = p.slab_stride;
         LOCATE_REQUIRE(total < (1ll << 31), "%s: split-K output of %lld elements exceeds the 32-bit index range", who, total);
         igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
@@ -1018,11 +1122,9 @@ static ConvGeom make_geom(const int* g) {
 
 // geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
 static size_t slab_floats(const IgParams& p, int nmax) {
-    int min_kpad = 1 << 30;
-    for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
-    int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
-    if (ks > min_kpad / IG_BK) ks = min_kpad / IG_BK;
-    return ks > 1 ? (size_t)ks * p.B * p.M * p.OH * p.OW : 0;
+    // the caller may or may not pass counters: room for whichever form the launch then takes
+    const size_t a = igemm_split_plan(p, nmax, false).slab_floats, b = igemm_split_plan(p, nmax, true).slab_floats;
+    return a > b ? a : b;
 }
 
 static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int* T) {
@@ -1166,8 +1268,8 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
 }
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
-                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, hipStream_t st,
-                     const char* who) {
+                     int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, unsigned* counters,
+                     hipStream_t st, const char* who) {
     IgParams p;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
@@ -1181,7 +1283,7 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
     }
     LOCATE_REQUIRE(scale_bg >= 0 && (scale_bg == 0 || g.B % scale_bg == 0), "%s: batch %d is not a multiple of the scale group %d", who, g.B, scale_bg);
     LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
-    return launch_igemm(p, nmax, ws, st, who);
+    return launch_igemm(p, nmax, ws, counters, st, who);
 }
 
 static size_t igemm_ws_bytes(const int* geom, int adjoint) {
@@ -1199,14 +1301,19 @@ LOCATE_API size_t locate_conv_dgrad_workspace_bytes(const int* geom) { return ig
 // x_bs / y_bs: batch strides in elements (channel-sliced views of a contiguous NCHW tensor are allowed).
 // scale (nullable): scale_group_batch = 0 -> one device scalar; > 0 -> batch element b uses
 // scale[(b / scale_group_batch) * scale_stride] (several forwards stacked along the batch, each with its own sigma).
+LOCATE_API size_t locate_conv_counter_bytes(void) { return IG_MAX_COUNTERS * sizeof(unsigned); }
+
+// counters (nullable): locate_conv_counter_bytes() bytes of device memory, ZERO before the first call that uses them and
+// left zero by every completed call, not shared by launches that may run concurrently.  With counters the split-K partial
+// tiles of mid-sized launches are combined inside the launch instead of by a second kernel.
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               void* workspace, void* stream) {
+                               void* workspace, void* counters, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
     return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
-                     as_stream(stream), "locate_conv_fwd");
+                     static_cast<unsigned*>(counters), as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
@@ -1214,12 +1321,12 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 void* workspace, void* stream) {
+                                 void* workspace, void* counters, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
     return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
-                     static_cast<float*>(workspace), as_stream(stream), "locate_conv_dgrad");
+                     static_cast<float*>(workspace), static_cast<unsigned*>(counters), as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -632,6 +632,22 @@ def _sigma_args(sigma, batch):
     return groups, batch // groups, sigma.stride(0), sigma[0, 1:]
 
 
+def _counters(owner, adjoint):
+    """Arrival counters of one layer and direction for the in-launch split-K combine (locate_conv_counter_bytes: zero at
+    creation, left zero by every launch).  Per layer, direction AND stream: the same layer may run on several streams at
+    once (three-stream D-step), and launches that can overlap must not share a block."""
+    cache = owner.__dict__.setdefault("_locate_counters", {})
+    key = (adjoint, torch.cuda.current_stream().cuda_stream if not torch.cuda.is_current_stream_capturing() else 0)
+    buf = cache.get(key)
+    if buf is None or buf.device != owner.device:
+        # (the block used under hipGraph capture - key 0 - is created together with the first eager one, so that a capture,
+        # which always follows eager warm-up iterations, never allocates or zero-fills anything here)
+        for k in {key, (adjoint, 0)}:
+            cache[k] = torch.zeros(lib().locate_conv_counter_bytes(), dtype=torch.uint8, device=owner.device)
+        buf = cache[key]
+    return buf
+
+
 def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
     """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode."""
     L = lib()
@@ -641,11 +657,11 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
         if forward_of_r:
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
             check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                    _bs(y), _p(ws), st), "locate_conv_fwd")
+                                    _bs(y), _p(ws), _p(_counters(owner, 0)), st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
             check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                      _bs(y), _p(ws), st), "locate_conv_dgrad")
+                                      _bs(y), _p(ws), _p(_counters(owner, 1)), st), "locate_conv_dgrad")
         return y
     if bias is not None:
         raise NotImplementedError("grouped convolutions carry no bias in the reference (libs/conv.py:15, libs/attention.py:18)")

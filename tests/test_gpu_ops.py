@@ -705,3 +705,38 @@ def test_conv_stage_linearity_at_benchmark_size(C, size):
         # (the rank-1 spectral-norm term dsigma u v^T is linear in g as well)
         grads.append(w.grad.clone())
     assert_close(grads[2].cpu(), (grads[0] + grads[1]).cpu(), 2e-5, "weight-gradient additivity")
+
+
+@pytest.mark.parametrize("C,size,B", [(768, 4, 64), (384, 8, 64), (96, 8, 2)])
+def test_split_k_combined_in_launch_is_reproducible_and_matches_the_reduction_kernel(C, size, B, monkeypatch):
+    """Split-K launches that combine their partial tiles inside the launch (arrival counters, last block sums in z order):
+    (1) bit-identical results over repeated launches while another stream keeps the chip unevenly busy and the consumer's
+    caches are warm (the hand-off must not depend on timing or placement), (2) the counters are left zero, (3) the same
+    values as the two-kernel path (partial tiles + reduction kernel) up to the fused multiply-add of the epilogue."""
+    from locate_amd import ops
+    torch.manual_seed(C + size)
+    w = (torch.randn(C, C, 4, 4, device=dev()) * 0.02)
+    u, v = torch.randn(C, device=dev()), torch.randn(C * 16, device=dev())
+    sigma, wv = torch.tensor([2.0, 0.5], device=dev()), torch.zeros(C, device=dev())
+    spec = ops.ConvSpec("convT", 4, 4, 2, 1, 1)
+    x = torch.randn(B, C, size, size, device=dev())
+    bias = torch.randn(C, device=dev())
+
+    def run():
+        with torch.no_grad():
+            return ops.SNConvFn.apply(x, w, u, v, bias, sigma, wv, spec)
+    first = run().clone()
+    side = torch.cuda.Stream()
+    junk = torch.randn(1 << 24, device=dev())
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 3):
+                junk.mul_(1.0001)                 # uneven background load on the other stream
+        again = run()
+        assert torch.equal(again, first), "launch %d differs" % it
+    torch.cuda.synchronize()
+    counters = w.__dict__["_locate_counters"]
+    assert counters and all(int(c.view(torch.int32).abs().sum()) == 0 for c in counters.values())
+    monkeypatch.setattr(ops, "_counters", lambda owner, adjoint: None)      # NULL counters: the reduction-kernel path
+    legacy = run()
+    assert_close(first.cpu(), legacy.cpu(), 1e-6, "in-launch combine vs reduction kernel")
