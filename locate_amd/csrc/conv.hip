@@ -510,6 +510,8 @@ __device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsig
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// NOTE (hipcc 7.2 / clang 22): __builtin_bit_cast applied DIRECTLY to an element of an ext_vector (`bit_cast(unsigned, v[k])`)
+// compiles to element 0 for every k.  Use __float_as_uint / __uint_as_float on vector elements, or copy to a scalar first.
 
 template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
@@ -823,8 +825,8 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     u32x4 v;
-                    v[0] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 0]); v[1] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 1]);
-                    v[2] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 2]); v[3] = __builtin_bit_cast(unsigned, acc[i][j][4 * q + 3]);
+                    v[0] = __float_as_uint(acc[i][j][4 * q + 0]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
+                    v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
                     __builtin_amdgcn_raw_buffer_store_b128(v, srs, (int)(my + (unsigned)(((i * TN + j) * 4 + q) * 256 * 16)), 0, 16);   // aux 16 = sc1
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -863,7 +865,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
                 for (int f = 0; f < HB; ++f) {
                     const int g = h0 + f, i = g / (TN * 4), j = (g / 4) % TN, q = g % 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += __builtin_bit_cast(float, v[f][e]);
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += __uint_as_float(v[f][e]);
                 }
             }
         }

@@ -44,7 +44,9 @@ class GraphedTrainStep:
         cap_stream = torch.cuda.Stream()     # ONE capture stream: autograd replays a node's backward on its forward's stream
         self.pool_b = torch.cuda.graph_pool_handle()
         self._side = torch.cuda.Stream()
-        self._e1, self._e2 = torch.cuda.Event(), torch.cuda.Event()
+        self._e0, self._e1, self._e2, self._es = (torch.cuda.Event() for _ in range(4))
+        self._keep = []
+        self.sn_graph = None
 
         def capture(fn, pool=None):
             g = torch.cuda.CUDAGraph()
@@ -62,6 +64,16 @@ class GraphedTrainStep:
         try:
             if self.overlap:
                 generated = capture(lambda: step.d_generate(lat))                              # 0
+                # The discriminator's three power iterations of the D-step (sigma for real / fake / augmented, main.py:149-152)
+                # read only what the PREVIOUS iteration left behind (D's weights after its optimizer step, u / v after the
+                # G-step's discriminator pass), so they are a graph of their own, replayed on the second stream beside the
+                # generator pass; the D-step's forward consumes the queued results.  Their output tensors are kept alive for
+                # the life of the graphs: they live in the second pool, which the G-step's generator pass also allocates from.
+                if step.stacked_d and getattr(step.dis, "batched_spectral_norm", False):
+                    self.sn_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.sn_graph, pool=self.pool_b, stream=cap_stream):
+                        step.dis.prefetch_spectral_norm(3)
+                    self._keep.extend(step.dis._sn_queue)
                 capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1
                 self._prime(step.dis_opt)
                 capture(step.d_optimizer)                                                      # 2
@@ -96,12 +108,19 @@ class GraphedTrainStep:
         if self.overlap:
             main = torch.cuda.current_stream()
             g = self.graphs
+            self._e0.record(main)                  # everything the previous iteration wrote is complete here
             g[0].replay()                          # D-step generator pass
             self._e1.record(main)
-            self._side.wait_event(self._e1)
             with torch.cuda.stream(self._side):
+                if self.sn_graph is not None:
+                    self._side.wait_event(self._e0)
+                    self.sn_graph.replay()         # D's three power iterations, beside the generator pass
+                    self._es.record(self._side)
+                self._side.wait_event(self._e1)
                 g[3].replay()                      # G-step generator pass, concurrent with the discriminator work below
                 self._e2.record(self._side)
+            if self.sn_graph is not None:
+                main.wait_event(self._es)
             g[1].replay()
             if red_d is not None:
                 red_d.reduce_now()

@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the stage name")
+    ap.add_argument("--no-counters", action="store_true", help="NULL arrival counters: split-K partial tiles summed by the reduction kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = lib()
@@ -77,13 +78,17 @@ def main():
         part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
         ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
 
+        cnt_f = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
+        cnt_d = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
+        use_cnt = not args.no_counters
+
         def r_fwd(inp, out):      # R forward
             check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                    out.stride(0), ws_f.data_ptr(), st))
+                                    out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, st))
 
         def r_dgrad(inp, out):    # R data adjoint
             check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                      out.stride(0), ws_d.data_ptr(), st))
+                                      out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, st))
 
         if kind == "conv":
             fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
