@@ -29,6 +29,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--image-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 (headline): the reference's arithmetic.  bf16: contraction operands rounded to bf16, one MFMA per "
+                         "slice, fp32 accumulation and storage (BASELINE configs[1] as named; tolerances in tests/test_gpu_bf16.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrent-d", action="store_true",
@@ -41,7 +44,7 @@ def parse():
     return ap.parse_args()
 
 
-def conv_roofline(cfg, batch, dev, reps=10):
+def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     """Dominant kernel: the implicit GEMM behind the generator's four C>=96 ConvTranspose 4x4 s2 stages (75 % of
     the step's FLOPs).  Algorithmic FLOPs per launch
     = 2 * B * (2H * 2W) * C_out * C_in * 4 taps (each output pixel of a 4x4 s2 p1 transposed conv has 2x2 taps);
@@ -53,6 +56,8 @@ def conv_roofline(cfg, batch, dev, reps=10):
     from locate_amd import ops
     from locate_amd.models import generator_features
     feats = generator_features(cfg)
+    rt = ops.Runtime()
+    rt.precision = 1 if bf16 else 0
     total_flops, total_ms, rows = 0.0, 0.0, []
     size = 2
     for i in range(len(feats) - 1):
@@ -66,11 +71,11 @@ def conv_roofline(cfg, batch, dev, reps=10):
             pre = ops.sn_power_iteration(w, u, v)
             with torch.no_grad():
                 for _ in range(2):
-                    ops.sn_conv(x, w, u, v, None, spec, pre)
+                    ops.sn_conv(x, w, u, v, None, spec, pre, rt)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    ops.sn_conv(x, w, u, v, None, spec, pre)
+                    ops.sn_conv(x, w, u, v, None, spec, pre, rt)
                 e1.record()
                 e1.synchronize()
             ms = e0.elapsed_time(e1) / reps
@@ -80,6 +85,11 @@ def conv_roofline(cfg, batch, dev, reps=10):
             total_ms += ms
         size *= 2
     achieved = total_flops / total_ms / 1e9 if total_ms > 0 else 0.0
+    if bf16:
+        return {"bound": "mfma", "kernel": "conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 "
+                                           "slice, fp32 accumulate, ConvTranspose 4x4 s2 fwd)",
+                "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+                "traffic": None, "per_stage": rows}
     peak = round(2500.0 / 6.0, 1)
     return {"bound": "mfma", "kernel": "conv_igemm_bx6_kernel (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per "
                                        "32x32x16 slice, ConvTranspose 4x4 s2 fwd)",
@@ -147,6 +157,8 @@ def main():
     G, GO = get_model(Generator(cfg), cfg.glr, dev)
     D, DO = get_model(Discriminator(cfg), cfg.dlr, dev)
     G.batched_spectral_norm = D.batched_spectral_norm = True
+    G.set_precision(args.dtype)
+    D.set_precision(args.dtype)
     red_g = red_d = None
     if world > 1:
         broadcast_module_state(G, 0, extra_tensors=[G.noise])
@@ -203,7 +215,9 @@ def main():
             "metric": "images/sec (G+D step) 64x64 bs=64", "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions: exact 3 x bf16 operand splits on the bf16 MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32 (contractions: exact 3 x bf16 operand splits on the bf16 MFMA, fp32 accumulate)" if args.dtype == "fp32" else
+                     "bf16 (contraction operands rounded to bf16, one MFMA per slice, fp32 accumulate; storage, statistics, "
+                     "sigma, activations and Nadam fp32) - NOT the headline line, see --dtype fp32", "data": "synthetic",
             "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (BASELINE.json configs[1]), "
                                    "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
@@ -212,7 +226,7 @@ def main():
                                  if use_graph else "eager (all-reduce overlapped with backward)"},
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }
-        line["roofline"] = conv_roofline(cfg, B, dev)
+        line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
         if S == 64:
             # step-level figures with SURVEY.md section 8(d)'s op-by-op accounting of the REFERENCE graph (7.5 GFLOP and
             # 356 MB fp32 per image at 64x64): effective rates - fusion that never materialises an intermediate counts

@@ -128,15 +128,19 @@ size_t locate_conv_fwd_workspace_bytes(const int* geom);
  * use, left zero by every completed call, never shared by launches that may run concurrently (one block per layer and
  * direction is what the Python layer keeps).  `counters` may be NULL: a second kernel then sums the partial tiles. */
 size_t locate_conv_counter_bytes(void);
-/* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride] */
+/* scale_group_batch = 0: `scale` is one scalar; > 0: batch element b uses scale[(b / scale_group_batch) * scale_stride].
+ * precision (locate_conv_fwd / _dgrad / _wgrad): 0 = fp32-faithful products (the reference's arithmetic: both operands split
+ * exactly into three bf16 pieces, six bf16 MFMAs per slice, fp32 accumulation); 1 = bf16 operands (both operands rounded to
+ * nearest-even bf16, one MFMA per slice, fp32 accumulation and fp32 storage) - the mixed-precision variant BASELINE.json
+ * configs[1] names; tolerance against the fp32 path stated in tests/test_gpu_bf16.py. */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                     int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
-                    void* counters, void* stream);
+                    void* counters, int precision, void* stream);
 /* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                       int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
-                      void* counters, void* stream);
+                      void* counters, int precision, void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.
@@ -146,7 +150,7 @@ size_t locate_conv_wgrad_workspace_bytes(const int* geom);
 int locate_conv_wgrad_partials(const int* geom);
 int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
-                      double* inner_partial, void* workspace, void* stream);
+                      double* inner_partial, void* workspace, int precision, void* stream);
 
 /* ---- grouped convolutions of the SEPARABLE switch (libs/config.py:53; replaces the torch.nn.Conv2d /
  *      ConvTranspose2d(groups = ...) forward + autograd backward under libs/conv.py:14-18 and libs/attention.py:15-21).

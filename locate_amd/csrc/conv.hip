@@ -218,6 +218,15 @@ __device__ __forceinline__ void split3_trunc_pair(float v0, float v1, unsigned& 
     l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l0), 0x07060302u);
 }
 
+// two fp32 values rounded to nearest-even bf16, packed (v0 in the low half)
+__device__ __forceinline__ unsigned round_bf16_pair(float v0, float v1) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t r;
+    r[0] = (__bf16)v0;
+    r[1] = (__bf16)v1;
+    return *reinterpret_cast<unsigned*>(&r);
+}
+
 __device__ __forceinline__ void split3_trunc_x8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
     split3_trunc_pair(v[0], v[1], h.x, m.x, l.x);
     split3_trunc_pair(v[2], v[3], h.y, m.y, l.y);
@@ -340,6 +349,7 @@ struct IgParams {
     int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab`
     float* slab;         //   combine == 0: dense [ksplit][B, M, OH, OW], summed by igemm_slab_reduce_kernel
     long long slab_stride;
+    int precision;       // 0: fp32-faithful (three bf16 pieces per operand, six MFMAs per slice); 1: bf16 operands (one piece)
     int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
     unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
     IgPhase ph[4];
@@ -652,7 +662,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // ---------------------------------------------------------------------------------------------
 #define B6_BK 16
 
-template <int WGM, int WGN, int TM, int TN>
+// NP = 3: the exact three-piece form above.  NP = 1: "bf16 operands" - both operands rounded (to nearest even) to ONE bf16
+// piece, one MFMA per slice, fp32 accumulation: the precision of a bf16 mixed-precision training step (BASELINE configs[1]),
+// a third of the LDS traffic and a sixth of the matrix work.  Storage stays fp32 on both sides of the kernel.
+template <int WGM, int WGN, int TM, int TN, int NP>
 __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p) {
     constexpr int BK = B6_BK, KB = BK / 8;
     constexpr int BM = WGM * TM * 32;
@@ -664,8 +677,15 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     // offset-table rows must lie inside the panel's zero tail
     static_assert(2 * BK <= IG_TAIL && (IG_TAIL % 8) == 0, "panel tail shorter than the prefetch distance");
 
-    __shared__ uint4 As[2][3][KB][BM];
-    __shared__ uint4 Bs[2][3][KB][BN];
+    // ONE LDS array (a second __shared__ object beside it can cost a vmcnt(0) per stage, cdna_hip_programming.md section 5):
+    // operand images of the K loop, then - they are dead after its last barrier - four 32 x 33 float patches of the staged
+    // epilogue and the split-K "I am last" word
+    constexpr int A_U4 = 2 * NP * KB * BM, B_U4 = 2 * NP * KB * BN;
+    constexpr int EPI_U4 = (4 * 32 * 33 + 8 + 3) / 4;
+    constexpr int SMEM_U4 = A_U4 + B_U4 > EPI_U4 ? A_U4 + B_U4 : EPI_U4;
+    __shared__ uint4 smem[SMEM_U4];
+    uint4 (*As)[NP][KB][BM] = reinterpret_cast<uint4 (*)[NP][KB][BM]>(smem);
+    uint4 (*Bs)[NP][KB][BN] = reinterpret_cast<uint4 (*)[NP][KB][BN]>(smem + A_U4);
 
     int bx, by, bz;
     xcd_tile(bx, by, bz);
@@ -719,8 +739,10 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + __builtin_amdgcn_readfirstlane(kidx));   // s_load_dwordx2
     auto issue_loads = [&]() {
         areg0 = ap[0];
-        areg1 = ap[a_plane];
-        areg2 = ap[2 * a_plane];
+        if constexpr (NP == 3) {
+            areg1 = ap[a_plane];
+            areg2 = ap[2 * a_plane];
+        }
         ap += a_step;
 #pragma unroll
         for (int j = 0; j < 8; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
@@ -732,17 +754,26 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     auto store_tiles = [&](int buf) {
         if (a_thread) {
             As[buf][0][a_kb][a_m] = areg0;
-            As[buf][1][a_kb][a_m] = areg1;
-            As[buf][2][a_kb][a_m] = areg2;
+            if constexpr (NP == 3) {
+                As[buf][NP - 2][a_kb][a_m] = areg1;
+                As[buf][NP - 1][a_kb][a_m] = areg2;
+            }
         }
-        uint4 h, m, l;
-        float v[8];
+        if constexpr (NP == 3) {
+            uint4 h, m, l;
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = breg[j];
-        split3_trunc_x8(v, h, m, l);
-        Bs[buf][0][kgrp][ncol] = h;
-        Bs[buf][1][kgrp][ncol] = m;
-        Bs[buf][2][kgrp][ncol] = l;
+            for (int j = 0; j < 8; ++j) v[j] = breg[j];
+            split3_trunc_x8(v, h, m, l);
+            Bs[buf][0][kgrp][ncol] = h;
+            Bs[buf][NP - 2][kgrp][ncol] = m;
+            Bs[buf][NP - 1][kgrp][ncol] = l;
+        } else {
+            bf16x8 h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (__bf16)breg[j];          // round to nearest even (v_cvt_pk_bf16_f32)
+            Bs[buf][0][kgrp][ncol] = *reinterpret_cast<uint4*>(&h);
+        }
     };
 
     // Software pipeline: while the matrix pipe works through the first half of a stage's MFMAs, the wave converts and
@@ -756,30 +787,35 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
-    constexpr int NMF = TM * TN * 6, HALF = NMF / 2;
+    constexpr int PROD = NP == 3 ? 6 : 1;
+    constexpr int NMF = TM * TN * PROD, HALF = NMF / 2;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        bf16x8 a[TM][3], b[TN][3];
+        bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][lrow][(wm * TM + i) * 32 + lcol]);
+            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][lrow][(wm * TM + i) * 32 + lcol]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][lrow][(wn * TN + j) * 32 + lcol]);
+            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][lrow][(wn * TN + j) * 32 + lcol]);
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int base = (i * TN + j) * 6;
-                    if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
-                    if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
-                    if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
-                    if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
-                    if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
-                    if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    const int base = (i * TN + j) * PROD;
+                    if constexpr (NP == 3) {
+                        if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                        if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);   // h l
+                        if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
+                        if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                        if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 2], acc[i][j], 0, 0, 0);   // h m
+                        if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    } else {
+                        if (base >= lo && base < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    }
                 }
         };
         __builtin_amdgcn_sched_barrier(0);
@@ -791,16 +827,18 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
         mfmas(HALF, NMF);
         // one vector-memory instruction (and its address arithmetic) in the shadow of every MFMA: the memory pipe takes
         // ~100 cycles per wave instruction when twelve waves queue on it, the matrix pipe 32 per MFMA
+        if constexpr (NP == 3) {
 #pragma unroll
-        for (int k = 0; k < NMF - HALF; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            for (int k = 0; k < NMF - HALF; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
         }
         __syncthreads();
     }
     // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
-    float* const stage = reinterpret_cast<float*>(&Bs[0][0][0][0]) + wid * (32 * 33);   // Bs: 24 KiB for every tile shape
+    float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * 33);
     bool combined = false;
     if (p.ksplit > 1 && p.combine) {
         // ---- split-K combined inside the launch (no reduction kernel, no slab in the output's layout) ----
@@ -831,7 +869,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        unsigned* const flag = reinterpret_cast<unsigned*>(&Bs[0][0][0][0]) + 6000;     // beyond the four 32 x 33 patches
+        unsigned* const flag = reinterpret_cast<unsigned*>(smem) + 4 * 32 * 33 + 4;     // beyond the four 32 x 33 patches
         if (tid == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = ticket == (unsigned)(p.ksplit - 1);
@@ -1053,7 +1091,7 @@ static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counter
     const long long legacy = ks > 1 ? (long long)ks * p.B * p.M * p.OH * p.OW : 0;
     const long long fused = ks > 1 ? (long long)ks * ntiles * tile_floats : 0;
     sp.combine = have_counters && ks > 1 && (long long)ks * tile_floats * 4 <= (512 << 10) && ntiles <= IG_MAX_COUNTERS &&
-                 fused * 4 < (1ll << 31) && !path_disabled("bx6") && !path_disabled("combine");
+                 fused * 4 < (1ll << 31) && (p.precision == 1 || !path_disabled("bx6")) && !path_disabled("combine");
     sp.slab_floats = (size_t)(sp.combine ? fused : legacy);
     return sp;
 }
@@ -1075,11 +1113,16 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     dim3 grid(sp.gx, sp.gy, p.nphase * p.ksplit);
     for (int i = 0; i < p.nphase; ++i)
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
-    if (!path_disabled("bx6")) {
-        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
-        else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
-        else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
-        else conv_igemm_bx6_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    if (p.precision == 1) {
+        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
+    } else if (!path_disabled("bx6")) {
+        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 3><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_bx6_kernel<1, 4, 1, 1, 3><<<grid, 256, 0, st>>>(p);
     } else {
         if (bm == 128) conv_igemm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_igemm_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
@@ -1271,8 +1314,10 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
                      int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, unsigned* counters,
-                     hipStream_t st, const char* who) {
+                     int precision, hipStream_t st, const char* who) {
+    LOCATE_REQUIRE(precision == 0 || precision == 1, "%s: precision must be 0 (fp32-faithful) or 1 (bf16 operands)", who);
     IgParams p;
+    p.precision = precision;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
@@ -1290,6 +1335,7 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
 
 static size_t igemm_ws_bytes(const int* geom, int adjoint) {
     IgParams p;
+    p.precision = 0;
     int nmax = 0;
     conv_plan(make_geom(geom), adjoint, nullptr, nullptr, p, &nmax, nullptr, false, nullptr);
     return (p.nphase > 0 ? slab_floats(p, nmax) : 0) * sizeof(float);
@@ -1310,12 +1356,12 @@ LOCATE_API size_t locate_conv_counter_bytes(void) { return IG_MAX_COUNTERS * siz
 // tiles of mid-sized launches are combined inside the launch instead of by a second kernel.
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               void* workspace, void* counters, void* stream) {
+                               void* workspace, void* counters, int precision, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
     return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
-                     static_cast<unsigned*>(counters), as_stream(stream), "locate_conv_fwd");
+                     static_cast<unsigned*>(counters), precision, as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
@@ -1323,12 +1369,12 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 void* workspace, void* counters, void* stream) {
+                                 void* workspace, void* counters, int precision, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
     return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
-                     static_cast<float*>(workspace), static_cast<unsigned*>(counters), as_stream(stream), "locate_conv_dgrad");
+                     static_cast<float*>(workspace), static_cast<unsigned*>(counters), precision, as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1569,7 +1615,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
                                       // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
                                       // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands (see conv_igemm_bx6_kernel)
 __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BR = WGN * TN * 32;
@@ -1577,8 +1623,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     constexpr int X_PT = BR / 32;
     static_assert(WGM * WGN == 4, "four waves");
 
-    __shared__ unsigned Gs[2][3][BM][WB_PITCH];
-    __shared__ unsigned Xs[2][3][BR][WB_PITCH];
+    __shared__ unsigned Gs[2][NP][BM][WB_PITCH];
+    __shared__ unsigned Xs[2][NP][BR][WB_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -1668,19 +1714,27 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
-            unsigned h, m, l;
-            split3_trunc_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
-            Gs[buf][0][sub + 32 * i][wcol] = h;
-            Gs[buf][1][sub + 32 * i][wcol] = m;
-            Gs[buf][2][sub + 32 * i][wcol] = l;
+            if constexpr (NP == 3) {
+                unsigned h, m, l;
+                split3_trunc_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
+                Gs[buf][0][sub + 32 * i][wcol] = h;
+                Gs[buf][NP - 2][sub + 32 * i][wcol] = m;
+                Gs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else {
+                Gs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(greg[i].x * gsc, greg[i].y * gsc);
+            }
         }
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
-            unsigned h, m, l;
-            split3_trunc_pair(xreg[i].x, xreg[i].y, h, m, l);
-            Xs[buf][0][sub + 32 * i][wcol] = h;
-            Xs[buf][1][sub + 32 * i][wcol] = m;
-            Xs[buf][2][sub + 32 * i][wcol] = l;
+            if constexpr (NP == 3) {
+                unsigned h, m, l;
+                split3_trunc_pair(xreg[i].x, xreg[i].y, h, m, l);
+                Xs[buf][0][sub + 32 * i][wcol] = h;
+                Xs[buf][NP - 2][sub + 32 * i][wcol] = m;
+                Xs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else {
+                Xs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(xreg[i].x, xreg[i].y);
+            }
         }
     };
 
@@ -1695,30 +1749,35 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         load_tiles(n_begin + WB_BK);                 // beyond n_end: every lane masked, nothing is read
     }
     __syncthreads();
-    constexpr int NMF = TM * TN * 6, HALF = NMF / 2;
+    constexpr int PROD = NP == 3 ? 6 : 1;
+    constexpr int NMF = TM * TN * PROD, HALF = NMF / 2;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        bf16x8 a[TM][3], b[TN][3];
+        bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int base = (i * TN + j) * 6;
-                    if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);   // l h
-                    if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);   // h l
-                    if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);   // m m
-                    if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // m h
-                    if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h m
-                    if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    const int base = (i * TN + j) * PROD;
+                    if constexpr (NP == 3) {
+                        if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                        if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);   // h l
+                        if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
+                        if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][0], acc[i][j], 0, 0, 0);   // m h
+                        if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 2], acc[i][j], 0, 0, 0);   // h m
+                        if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    } else {
+                        if (base >= lo && base < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    }
                 }
         };
         __builtin_amdgcn_sched_barrier(0);
@@ -1830,9 +1889,10 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
 // (stacked forwards; at most 4 groups; w_ref / inner_partial must then be null - see locate_sn_group_dsigma).
 LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                                  const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
-                                 double* inner_partial, void* workspace, void* stream) {
+                                 double* inner_partial, void* workspace, int precision, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
+    LOCATE_REQUIRE(precision == 0 || precision == 1, "locate_conv_wgrad: precision must be 0 (fp32-faithful) or 1 (bf16 operands)");
     LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
     LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
     LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
@@ -1861,11 +1921,16 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     // pairs of adjacent reduction elements: same image and same output row, 8-byte aligned in gy
     const bool pairs_ok = ((g.OH * g.OW) & 1) == 0 && (g.OW & 1) == 0 && (gy_bs & 1) == 0 && (chunk & 1) == 0 &&
                           (reinterpret_cast<uintptr_t>(gy) & 7) == 0 && x_extent > 0 && x_extent < (1ll << 31) - (1 << 20);
-    if (pairs_ok && !path_disabled("wbx6")) {
-        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
-        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
-        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
-        else conv_wgrad_bx6_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
+    if (pairs_ok && precision == 1) {
+        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
+        else conv_wgrad_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
+    } else if (pairs_ok && !path_disabled("wbx6")) {
+        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 3><<<grid, 256, 0, st>>>(p);
+        else conv_wgrad_bx6_kernel<1, 4, 1, 1, 3><<<grid, 256, 0, st>>>(p);
     } else if (bm == 128) conv_wgrad_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
     else if (bm == 96) conv_wgrad_kernel<1, 4, 3, 1><<<grid, 256, 0, st>>>(p);
     else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);

@@ -99,6 +99,13 @@ class SpectralNormBatch:
 class _NetBase(nn.Module):
     batched_spectral_norm = False   # see SpectralNormBatch; off by default (per-layer update inside each layer)
 
+    def set_precision(self, name):
+        """"fp32": the reference's arithmetic (default; contractions as exact three-piece bf16 splits, six MFMAs per slice).
+        "bf16": contraction operands rounded to bf16, one MFMA per slice, fp32 accumulation; everything else - storage,
+        statistics, sigma, RootTanh, the optimizer - stays fp32 (the mixed-precision variant BASELINE.json configs[1] names)."""
+        self.runtime.precision = {"fp32": 0, "f32": 0, "bf16": 1}[name]
+        return self
+
     def adopt(self):
         """Gives the network its own ops.Runtime (stacked-call count, backward-pass deferrals) and points every layer that
         needs one at it - called at the end of the constructors.  Two networks therefore never share mutable host state."""

@@ -96,6 +96,7 @@ class Runtime:
     its `.grad` buffers anyway."""
 
     def __init__(self):
+        self.precision = 0               # contractions: 0 = fp32-faithful (the reference's arithmetic), 1 = bf16 operands
         self.stacked = 1                 # forward: the batch holds this many independent calls (main.py:149-152 as one pass)
         self.weight_grad_stream = None   # backward: weight gradients are launched on this stream (None: in line)
         self._dv_layers = {}             # id(v) -> (v, u, w, h, wd, state): layers whose dv is still to be finalised
@@ -107,7 +108,9 @@ class Runtime:
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
     def __deepcopy__(self, memo):
-        return Runtime()
+        rt = Runtime()
+        rt.precision = self.precision
+        return rt
 
     def stacked_calls(self, n):
         return _Stacked(self, n)
@@ -648,7 +651,7 @@ def _counters(owner, adjoint):
     return buf
 
 
-def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
+def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0):
     """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode."""
     L = lib()
     st = _stream()
@@ -657,11 +660,11 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
         if forward_of_r:
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
             check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                    _bs(y), _p(ws), _p(_counters(owner, 0)), st), "locate_conv_fwd")
+                                    _bs(y), _p(ws), _p(_counters(owner, 0)), precision, st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
             check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                      _bs(y), _p(ws), _p(_counters(owner, 1)), st), "locate_conv_dgrad")
+                                      _bs(y), _p(ws), _p(_counters(owner, 1)), precision, st), "locate_conv_dgrad")
         return y
     if bias is not None:
         raise NotImplementedError("grouped convolutions carry no bias in the reference (libs/conv.py:15, libs/attention.py:18)")
@@ -677,27 +680,27 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y):
     return y
 
 
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape):
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0):
     """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
     y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y)
+    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision)
 
 
-def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma):
+def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0):
     """Gradient w.r.t. the layer input."""
     if spec.mode == "groupdot":
         gy = gy.contiguous()
-    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like))
+    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like), precision)
 
 
-def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial):
+def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0):
     """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>."""
     L = lib()
     st = _stream()
     if spec.mode == "dense":
         ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), xin.device)
         check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial),
-                                  _p(ws), st), "locate_conv_wgrad")
+                                  _p(ws), precision, st), "locate_conv_wgrad")
     elif spec.mode == "depthwise":
         ws = _ws(L.locate_dwconv_wgrad_workspace_bytes(garr), xin.device)
         check(L.locate_dwconv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst,
@@ -733,7 +736,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
-        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None)
+        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision)
         dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
         gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
         Bn, Mn = gy.shape[0], gy.shape[1]
@@ -746,7 +749,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     # then the rank-1 spectral-norm correction in place
     npart = _weight_grad_partials(spec, geom, garr)
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
-    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial)
+    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision)
     dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
     check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
           "locate_sn_weight_bwd")
@@ -783,7 +786,8 @@ class SNConvFn(torch.autograd.Function):
         geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
         garr = _geom(geom)
         b = _c(bias) if bias is not None else None
-        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape)
+        rt = rt or DEFAULT_RUNTIME
+        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
         ctx.groups = groups
         if groups > 1:
@@ -792,7 +796,7 @@ class SNConvFn(torch.autograd.Function):
             ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.owner = owner
-        ctx.rt = rt or DEFAULT_RUNTIME
+        ctx.rt = rt
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
         return y
 
@@ -808,7 +812,7 @@ class SNConvFn(torch.autograd.Function):
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
         gx = gw = gu = gb = None
         if need_x:
-            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma)
+            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma, ctx.rt.precision)
         if need_w or need_u or need_v:
             rt = ctx.rt
             side = rt.weight_grad_stream

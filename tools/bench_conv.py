@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the stage name")
+    ap.add_argument("--bf16", action="store_true", help="bf16 operands (precision 1) instead of the fp32-faithful splits")
     ap.add_argument("--no-counters", action="store_true", help="NULL arrival counters: split-K partial tiles summed by the reduction kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -81,23 +82,24 @@ def main():
         cnt_f = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
         cnt_d = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
         use_cnt = not args.no_counters
+        prec = 1 if args.bf16 else 0
 
         def r_fwd(inp, out):      # R forward
             check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                    out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, st))
+                                    out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, st))
 
         def r_dgrad(inp, out):    # R data adjoint
             check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                      out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, st))
+                                      out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, st))
 
         if kind == "conv":
             fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, st))
         else:
             fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
             wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), st))
+                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, st))
         OH = out_shape[2]
         if kind == "conv":
             flops = 2.0 * B * OH * OH * cout * cin * k * k
