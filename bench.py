@@ -164,9 +164,13 @@ def main():
         broadcast_module_state(G, 0, extra_tensors=[G.noise])
         broadcast_module_state(D, 0)
         late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
-        red_g, red_d = GradAllReducer(G.parameters()), GradAllReducer(D.parameters(), late=late_v)
+        # the D-step's backward runs in two segments cut behind the discriminator's block 2 (maps >= 8x8 | <= 4x4): the deep
+        # segment holds ~95 % of D's parameters and is on the wire while the high-resolution segment's backward runs
+        d_cut = 3 if len(D.main[1].blocks) > 3 else None
+        red_g = GradAllReducer(G.parameters())
+        red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None)
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
-                     overlap_wgrad=args.wgrad_overlap)
+                     overlap_wgrad=args.wgrad_overlap, d_cut=d_cut if world > 1 else None)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)
@@ -194,6 +198,22 @@ def main():
         out = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    comm = None
+    if world > 1:
+        # a few extra steps with HIP events around the exchange: how much of it hides behind backward work
+        red_g.timing = red_d.timing = True
+        for _ in range(5):
+            one_step()
+        tg, xg = red_g.pop_timing()
+        td, xd = red_d.pop_timing()
+        red_g.timing = red_d.timing = False
+        comm = {"allreduce_ms_per_step": {"D": round(td / 5, 4), "G": round(tg / 5, 4)},
+                "exposed_ms_per_step": {"D": round(xd / 5, 4), "G": round(xg / 5, 4)},
+                "payload_MB": {"D": round(sum(p.numel() for p in D.parameters()) * 4 / 1e6, 1),
+                               "G": round(sum(p.numel() for p in G.parameters()) * 4 / 1e6, 1)},
+                "note": "side-stream time of pack + RCCL all-reduce + unpack per optimizer step, and the part of it the compute "
+                        "stream had to wait for; D's deep segment (blocks 3.. + head, ~95 % of its parameters) is sent while "
+                        "the high-resolution segment's backward runs, G's widest layers are the last its backward produces"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,10 +242,12 @@ def main():
                                    "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" + ("" if args.no_overlap else ", G-step generator pass on a second stream")
-                                  + (" + eager RCCL all-reduce between graphs" if world > 1 else ""))
+                                  + (" + bucketed RCCL all-reduce on a side stream between the graphs of the segmented backward" if world > 1 else ""))
                                  if use_graph else "eager (all-reduce overlapped with backward)"},
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }
+        if comm is not None:
+            line["data_parallel"] = comm
         line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
         if S == 64:
             # step-level figures with SURVEY.md section 8(d)'s op-by-op accounting of the REFERENCE graph (7.5 GFLOP and

@@ -666,13 +666,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // piece, one MFMA per slice, fp32 accumulation: the precision of a bf16 mixed-precision training step (BASELINE configs[1]),
 // a third of the LDS traffic and a sixth of the matrix work.  Storage stays fp32 on both sides of the kernel.
 template <int WGM, int WGN, int TM, int TN, int NP>
-__global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p) {
+__global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_kernel(const IgParams p) {
     constexpr int BK = B6_BK, KB = BK / 8;
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
     static_assert(WGM * WGN == 4, "four waves");
     static_assert(BN == 128 && KB * BN == 256, "one gathered fragment (k-block) per thread and stage");
-    static_assert(KB * BM <= 256, "at most one weight fragment per thread and stage");
+    static_assert(KB * BM <= 512, "at most two weight fragments per thread and stage");
+    constexpr bool A2 = KB * BM > 256;      // tall tiles (BM = 192: 64 x 96 per wave, twice the MFMAs per gathered element)
     // the pipeline issues the loads of two stages beyond the last one (tiles nsteps and nsteps + 1): their weight chunks and
     // offset-table rows must lie inside the panel's zero tail
     static_assert(2 * BK <= IG_TAIL && (IG_TAIL % 8) == 0, "panel tail shorter than the prefetch distance");
@@ -729,9 +730,14 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
     // launch_igemm), and the columns M .. ld - 1 are zero - no masking in the loop
     const uint4* ap = ph.w3 + (long long)(step0 * KB + a_kb) * ph.ld + (m0 + a_m);
     const long long a_step = (long long)KB * ph.ld, a_plane = ph.w3_plane;
+    // second weight fragment of tall tiles: chunk index tid + 256
+    const bool b_thread = A2 && tid + 256 < KB * BM;
+    const int b_kb = b_thread ? (tid + 256) / BM : 0, b_m = b_thread ? (tid + 256) % BM : 0;
+    const uint4* bp = ph.w3 + (long long)(step0 * KB + b_kb) * ph.ld + (m0 + b_m);
     int kidx = step0 * BK + kgrp * 8;                             // wave-uniform first table row of the next load
 
     uint4 areg0, areg1, areg2;     // three named registers: as an array this spills to scratch (clang keeps it in memory)
+    uint4 areg3, areg4, areg5;
     float breg[8];
     // the offset-table rows are fetched one stage ahead of the gather that uses them: the scalar load's round trip is
     // then off the per-stage critical path (it used to sit in front of every stage's buffer loads)
@@ -744,6 +750,14 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
             areg2 = ap[2 * a_plane];
         }
         ap += a_step;
+        if constexpr (A2) {
+            areg3 = bp[0];
+            if constexpr (NP == 3) {
+                areg4 = bp[a_plane];
+                areg5 = bp[2 * a_plane];
+            }
+            bp += a_step;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) breg[j] = gather_load(gc, offs[j], (unsigned)(taps >> (8 * j)) & 31u);
         kidx += BK;
@@ -757,6 +771,15 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_bx6_kernel(const IgParams p
             if constexpr (NP == 3) {
                 As[buf][NP - 2][a_kb][a_m] = areg1;
                 As[buf][NP - 1][a_kb][a_m] = areg2;
+            }
+        }
+        if constexpr (A2) {
+            if (b_thread) {
+                As[buf][0][b_kb][b_m] = areg3;
+                if constexpr (NP == 3) {
+                    As[buf][NP - 2][b_kb][b_m] = areg4;
+                    As[buf][NP - 1][b_kb][b_m] = areg5;
+                }
             }
         }
         if constexpr (NP == 3) {
@@ -1034,6 +1057,17 @@ static void launch_pointwise(const IgParams& p, hipStream_t st) {
     else launch_pointwise_px<1>(p, st);
 }
 
+// Tile height of the implicit-GEMM launch.  Tall 192 x 128 tiles (each wave 96 x 64: twice the MFMAs per gathered, split and
+// LDS-written activation element, two blocks per CU) for the wide layers when the launch still fills the chip with them.
+static int pick_bm(int M);
+static int igemm_bm(int M, int nmax, int nphase) {
+    if (M % 192 == 0 && M >= 192 && !path_disabled("tall") && !path_disabled("bx6")) {
+        const long long tiles = (long long)((nmax + 127) / 128) * (M / 192) * nphase;
+        if (tiles >= 128) return 192;
+    }
+    return pick_bm(M);
+}
+
 static int pick_bm(int M) {
     const int cands[4] = {128, 96, 64, 32};
     int best = 128, best_pad = 1 << 30;
@@ -1047,12 +1081,13 @@ static int pick_bm(int M) {
 // Split K over extra blocks when the (M, N) tiling alone cannot fill 256 CUs (deep discriminator layers and the
 // first generator stages: N = B*OH*OW is only 64 ... 1024 there while K = C*KH*KW is up to 12 800).
 static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
-    const int bm = pick_bm(M);
+    const int bm = igemm_bm(M, nmax, nphase);
     const long long tiles = (long long)((nmax + 127) / 128) * ((M + bm - 1) / bm) * nphase;
-    // 256 CUs x ~3 resident blocks: launches of >= 768 blocks, or an exact multiple of 256 from 512 up, are balanced
-    if (tiles >= 768 || (tiles >= 512 && tiles % 256 == 0)) return 1;
+    const int slots = bm == 192 ? 512 : 768;        // resident blocks: 256 CUs x 2 (tall tiles) or x 3
+    // launches of >= one full round of resident blocks, or an exact multiple of 256 from 512 up, are balanced
+    if (tiles >= slots || (tiles >= 512 && tiles % 256 == 0)) return 1;
     const int steps = min_kpad / IG_BK;
-    long long want = (768 + tiles - 1) / tiles;
+    long long want = (slots + tiles - 1) / tiles;
     // at least 8 K steps (128 reduction elements) per block - 2 when the output is tiny (the style linears, the deep
     // discriminator layers at batch-sized N): those launches are a latency chain of K steps on a handful of blocks and
     // their partial tiles cost next to nothing
@@ -1077,7 +1112,7 @@ struct SplitPlan {
 
 static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counters) {
     SplitPlan sp;
-    const int bm = pick_bm(p.M);
+    const int bm = igemm_bm(p.M, nmax, p.nphase);
     int min_kpad = 1 << 30;
     for (int i = 0; i < p.nphase; ++i) min_kpad = p.ph[i].Kpad < min_kpad ? p.ph[i].Kpad : min_kpad;
     int ks = igemm_ksplit(p.M, nmax, p.nphase, min_kpad);
@@ -1103,7 +1138,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
         LOCATE_LAUNCH_CHECK(who);
         return LOCATE_OK;
     }
-    const int bm = pick_bm(p.M);
+    const int bm = igemm_bm(p.M, nmax, p.nphase);
     const SplitPlan sp = igemm_split_plan(p, nmax, counters != nullptr);
     p.ksplit = sp.ksplit;
     p.combine = sp.combine;
@@ -1114,12 +1149,14 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     for (int i = 0; i < p.nphase; ++i)
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
     if (p.precision == 1) {
-        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_igemm_bx6_kernel<2, 2, 3, 2, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
         else conv_igemm_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
     } else if (!path_disabled("bx6")) {
-        if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_igemm_bx6_kernel<2, 2, 3, 2, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 3><<<grid, 256, 0, st>>>(p);
         else conv_igemm_bx6_kernel<1, 4, 1, 1, 3><<<grid, 256, 0, st>>>(p);

@@ -47,6 +47,7 @@ class GraphedTrainStep:
         self._e0, self._e1, self._e2, self._es = (torch.cuda.Event() for _ in range(4))
         self._keep = []
         self.sn_graph = None
+        self.d_tail = None
 
         def capture(fn, pool=None):
             g = torch.cuda.CUDAGraph()
@@ -74,7 +75,15 @@ class GraphedTrainStep:
                     with torch.cuda.graph(self.sn_graph, pool=self.pool_b, stream=cap_stream):
                         step.dis.prefetch_spectral_norm(3)
                     self._keep.extend(step.dis._sn_queue)
-                capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1
+                if step.d_cut is not None:
+                    # data parallel: the D-step's backward as two graphs; replay() launches the deep segment's all-reduce
+                    # between them, so that it runs beside the second segment
+                    capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated, segment=0))   # 1
+                    self.d_tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.d_tail, pool=self.pool, stream=cap_stream):
+                        step.d_forward_backward(lat, real_, aug_, segment=1)
+                else:
+                    capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1
                 self._prime(step.dis_opt)
                 capture(step.d_optimizer)                                                      # 2
                 fake = capture(lambda: step.g_forward(lat), pool=self.pool_b)                  # 3 (second stream)
@@ -121,14 +130,22 @@ class GraphedTrainStep:
                 self._e2.record(self._side)
             if self.sn_graph is not None:
                 main.wait_event(self._es)
-            g[1].replay()
             if red_d is not None:
-                red_d.reduce_now()
+                red_d.begin_replay()
+            g[1].replay()
+            if self.d_tail is not None:
+                if red_d is not None:
+                    red_d.launch_group(0)          # deep segment's gradients: on the wire beside the second segment
+                self.d_tail.replay()
+            if red_d is not None:
+                red_d.finish()                     # remaining buckets, then the compute stream joins the side stream
             g[2].replay()
             main.wait_event(self._e2)
+            if red_g is not None:
+                red_g.begin_replay()
             g[4].replay()
             if red_g is not None:
-                red_g.reduce_now()
+                red_g.finish()
             g[5].replay()
         else:
             self.graphs[0].replay()

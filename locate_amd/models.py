@@ -186,15 +186,45 @@ class Discriminator(_NetBase):
         self.main = nn.Sequential(stem, block_block, head)
         self.adopt()
 
-    def forward(self, function_input, stacked=1):
+    def forward(self, function_input, stacked=1, cut_after=None):
         """stacked = k > 1: `function_input` stacks k independent calls along the batch (k equal slices); the result
         equals running them one after the other (k power iterations in order, per-call InPlaceNorm statistics), in
-        one pass over the network - the three D passes of the reference's D-step (main.py:149-152)."""
+        one pass over the network - the three D passes of the reference's D-step (main.py:149-152).
+
+        cut_after = j: the same values, but as TWO autograd graphs cut behind block j - 1 of the stack, so that the backward
+        pass can be run (and captured, and its gradients sent to the other ranks) in two segments: first
+        `backward(out, g)` through the head and the blocks j.., then `backward(*self.take_cut())` through the blocks ..j - 1
+        and the stem.  The deep, narrow-map segment holds ~95 % of the discriminator's parameters, the other one most of
+        its time: the first segment's all-reduce hides behind the second segment's backward (locate_amd.parallel)."""
         self._sn_prologue(stacked)
-        if stacked == 1:
-            return self.main(function_input)
         with self.runtime.stacked_calls(stacked):
-            return self.main(function_input)
+            if cut_after is None:
+                return self.main(function_input)
+            stem, stack, head = self.main
+            if stack.mul_blocks or not 0 < cut_after <= len(stack.blocks):
+                raise ValueError("cut_after must name a block boundary of the discriminator stack")
+            h = stem(function_input)
+            for block in stack.blocks[:cut_after]:
+                h = block(h)
+            h_in = h.detach().requires_grad_(True)
+            out = h_in
+            for block in stack.blocks[cut_after:]:
+                out = block(out)
+            object.__setattr__(self, "_cut", (h, h_in))
+            return head(out)
+
+    def take_cut(self):
+        """(tensor, gradient) for the second backward segment of a cut forward: call after the first segment's backward."""
+        h, h_in = self._cut
+        object.__setattr__(self, "_cut", None)
+        return h, h_in.grad
+
+    def segment_parameters(self, cut_after):
+        """The parameters of the two backward segments, in the order their gradients become complete."""
+        stem, stack, head = self.main
+        late = [p for m in list(stack.blocks[cut_after:]) + [head] for p in m.parameters()]
+        early = [p for m in [stem] + list(stack.blocks[:cut_after]) for p in m.parameters()]
+        return [late, early]
 
 
 def init(module):

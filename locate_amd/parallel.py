@@ -27,10 +27,14 @@ def broadcast_module_state(module, src=0, extra_tensors=()):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None, groups=None):
         """`late`: predicate (or collection) of parameters whose .grad is only assigned at the very end of the backward
         pass, outside autograd's accumulation (the spectral-norm v vectors, ops.Runtime._finalize_dv).  They get buckets
-        of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients."""
+        of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients.
+        `groups`: parameter collections in the order their gradients become complete when the backward pass is run in
+        SEGMENTS (Discriminator.forward(cut_after=...)): buckets never span two groups, so `launch_group(i)` can send a
+        finished segment's gradients while the next segment's backward is still running - the form the hipGraph replay
+        uses, where post-accumulate hooks do not exist."""
         self.params = [p for p in params]
         if late is None:
             is_late = [False] * len(self.params)
@@ -40,27 +44,49 @@ class GradAllReducer:
             late_ids = {id(p) for p in late}
             is_late = [id(p) in late_ids for p in self.params]
         self.is_late = is_late
+        group_of = [0] * len(self.params)
+        if groups is not None:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            seen = set()
+            for gi, members in enumerate(groups):
+                for p in members:
+                    i = index.get(id(p))
+                    if i is not None:
+                        group_of[i] = gi
+                        seen.add(i)
+            last = len(groups)
+            for i in range(len(self.params)):
+                if i not in seen:
+                    group_of[i] = last              # anything not listed: a trailing group of its own
+        self.group_of = group_of
+        self.n_groups = max(group_of) + 1 if group_of else 1
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         self.bucket_bytes = bucket_bytes
         # reverse order ~ gradient production order
         self.buckets = []          # list of lists of parameter indices
-        cur, cur_bytes = [], 0
-        for group_late in (False, True):
-            cur, cur_bytes = [], 0
-            for idx in reversed(range(len(self.params))):
-                if is_late[idx] != group_late:
-                    continue
-                p = self.params[idx]
-                nbytes = p.numel() * p.element_size()
-                if cur and cur_bytes + nbytes > bucket_bytes:
+        self.bucket_group = []     # segment group of each bucket
+        for gi in range(self.n_groups):
+            for group_late in (False, True):
+                cur, cur_bytes = [], 0
+                for idx in reversed(range(len(self.params))):
+                    if is_late[idx] != group_late or group_of[idx] != gi:
+                        continue
+                    p = self.params[idx]
+                    nbytes = p.numel() * p.element_size()
+                    if cur and cur_bytes + nbytes > bucket_bytes:
+                        self.buckets.append(cur)
+                        self.bucket_group.append(gi)
+                        cur, cur_bytes = [], 0
+                    cur.append(idx)
+                    cur_bytes += nbytes
+                if cur:
                     self.buckets.append(cur)
-                    cur, cur_bytes = [], 0
-                cur.append(idx)
-                cur_bytes += nbytes
-            if cur:
-                self.buckets.append(cur)
+                    self.bucket_group.append(gi)
+        # RCCL averages in the collective itself; gloo (CPU tests, single-GPU rehearsals) sums and scales afterwards
+        backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self._avg = backend == "nccl"
         self.bucket_of = {}
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
@@ -73,6 +99,11 @@ class GradAllReducer:
         self._side = None
         self._hooks = []
         self._hooked = set()
+        # optional timing (bench.py): HIP events around every bucket's pack -> all-reduce -> unpack on the side stream, and
+        # around the compute stream's join in finish() - the part of the exchange that is NOT hidden behind backward work
+        self.timing = False
+        self._t_comm = []          # (start, end) event pairs on the side stream
+        self._t_wait = []          # (start, end) event pairs on the compute stream
 
     def remove_hooks(self):
         for h in self._hooks:
@@ -127,12 +158,37 @@ class GradAllReducer:
                 self._side = torch.cuda.Stream(device=dev)
             self._side.wait_stream(torch.cuda.current_stream(dev))   # the gradients are produced on the compute stream
             with torch.cuda.stream(self._side):
+                if self.timing:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(self._side)
+                    self._t_comm.append([ev, None])
                 self._pack(flat, grads)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         else:
             self._pack(flat, grads)
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         self._handles.append((b, members, work))
+
+    def _op(self):
+        return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+
+    # ---- segment-driven form (hipGraph replay: no hooks) --------------------------------------------------------
+    def begin_replay(self):
+        """Before replaying a captured backward: nothing is launched yet."""
+        if self.world == 1:
+            return
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._active = False
+
+    def launch_group(self, gi):
+        """Every gradient of segment group `gi` is complete on the current stream: send its buckets now, on the side
+        stream (the next segment's backward, replayed right after this call, runs beside them)."""
+        if self.world == 1:
+            return
+        for b, g in enumerate(self.bucket_group):
+            if g == gi and not self._launched[b]:
+                self._launch(b)
 
     @staticmethod
     def _views(flat, grads):
@@ -156,7 +212,7 @@ class GradAllReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        inv = 1.0 / self.world
+        inv = None if self._avg else 1.0 / self.world
         for b, members, work in self._handles:
             flat = self._flat[b]
             dev = flat.device
@@ -164,12 +220,36 @@ class GradAllReducer:
                 with torch.cuda.stream(self._side):
                     work.wait()
                     self._unpack(flat, members, inv)
+                    if self.timing:
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(self._side)
+                        for rec in self._t_comm:
+                            if rec[1] is None:
+                                rec[1] = ev
+                                break
             else:
                 work.wait()
                 self._unpack(flat, members, inv)
         if self._side is not None:
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            cur = torch.cuda.current_stream(self._side.device)
+            if self.timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self._side)
+                b.record(cur)
+                self._t_wait.append((a, b))
+            else:
+                cur.wait_stream(self._side)
         self._handles = []
+
+    def pop_timing(self):
+        """(side-stream milliseconds spent on the exchange, milliseconds the compute stream waited for it) since the last
+        call; synchronises the device.  exposed / total is the fraction of the exchange NOT hidden behind backward work."""
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._t_comm if b is not None)
+        exposed = sum(a.elapsed_time(b) for a, b in self._t_wait)
+        self._t_comm, self._t_wait = [], []
+        return total, exposed
 
     def reduce_now(self):
         """Non-overlapped form: average every existing .grad across the ranks right now, on the current stream.
@@ -177,7 +257,7 @@ class GradAllReducer:
         overlap is not available; at config 2 the payload is 47 / 56 MB, ~1 ms of a 25 ms step over xGMI."""
         if self.world == 1:
             return
-        inv = 1.0 / self.world
+        inv = None if self._avg else 1.0 / self.world
         for b, idxs in enumerate(self.buckets):
             members = [i for i in idxs if self.params[i].grad is not None]
             if not members:
@@ -189,12 +269,13 @@ class GradAllReducer:
                 flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
                 self._flat[b] = flat
             self._pack(flat, grads)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(flat, op=self._op(), group=self.group)
             self._unpack(flat, members, inv)
 
     def _unpack(self, flat, members, inv):
         grads = [self.params[i].grad for i in members]
-        flat.mul_(inv)
+        if inv is not None:
+            flat.mul_(inv)
         if all(g.is_contiguous() for g in grads):
             torch._foreach_copy_(grads, self._views(flat, grads))
         else:

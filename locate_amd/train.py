@@ -44,8 +44,13 @@ def g_loss(d_fake):
 
 class TrainStep:
     def __init__(self, gen, dis, gen_opt, dis_opt, penalty_gamma=100.0, minibatches=1, reducer_g=None, reducer_d=None,
-                 concurrent_d=False, stacked_d=None, overlap_wgrad=False):
+                 concurrent_d=False, stacked_d=None, overlap_wgrad=False, d_cut=None):
         self.gen, self.dis, self.gen_opt, self.dis_opt = gen, dis, gen_opt, dis_opt
+        # d_cut = j (data parallel): the stacked D-step's backward runs in two segments cut behind block j - 1 of the
+        # discriminator stack (Discriminator.forward(cut_after=j)); the reducer sends the first segment's gradients - the
+        # deep layers, ~95 % of D's parameters - while the second segment's backward runs.  Same values as one pass.
+        self.d_cut = d_cut
+        self._d_pending = None
         # overlap_wgrad: the weight gradients of a backward pass run on a second stream beside its chain of input gradients
         # (ops.Runtime.weight_grads_on); same values, the parameters' .grad are complete when backward() returns.  Off by
         # default: measured neutral under hipGraph replay (12.76 vs 12.74 ms at config 2 - the fork/join branches of one
@@ -114,24 +119,42 @@ class TrainStep:
         with torch.no_grad():
             return self.gen(latent)
 
-    def d_forward_backward(self, latent, real, aug, generated=None):
-        """`generated`: result of d_generate(latent) when that phase ran on its own (graph.py), else computed here."""
+    def d_forward_backward(self, latent, real, aug, generated=None, segment=None):
+        """`generated`: result of d_generate(latent) when that phase ran on its own (graph.py), else computed here.
+        segment (only with d_cut): 0 = forward, loss and the first backward segment; 1 = the second backward segment;
+        None = both.  graph.py captures the two segments as separate hipGraphs and launches the first segment's
+        all-reduce between their replays."""
         gen, dis = self.gen, self.dis
+        if segment == 1:
+            h, gh = dis.take_cut()
+            self._backward([h], [gh])
+            out, self._d_pending = self._d_pending, None
+            return out
         dis.zero_grad()                            # main.py:148
         if self.stacked_d and getattr(dis, "batched_spectral_norm", False):
             if generated is None:
                 generated = self.d_generate(latent)
             B = real.shape[0]
-            d_all = dis(torch.cat([real, generated, aug], dim=0), stacked=3)   # :149, :150, grad_penalty.py:2 in one pass
+            cut = self.d_cut
+            d_all = dis(torch.cat([real, generated, aug], dim=0), stacked=3, cut_after=cut)   # :149, :150, grad_penalty.py:2
             d_true, d_fake, d_aug = d_all[:B], d_all[B:2 * B], d_all[2 * B:]
             losses, g_t, _, _ = d_loss(d_true, d_fake, d_aug, self.penalty_gamma)
+            out = {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
+                   "d_gen": -d_fake.detach().view(-1), "generated": generated}
             if self.reducer_d is not None:
                 self.reducer_d.begin()
             self._backward([d_all], [g_t._base.view_as(d_all)])                 # :156
+            if cut is not None:
+                if segment == 0:
+                    self._d_pending = out
+                    return out
+                h, gh = dis.take_cut()
+                self._backward([h], [gh])
             if self.reducer_d is not None:
                 self.reducer_d.finish()
-            return {"d_error": losses[0], "penalty": losses[1], "d_true": d_true.detach().view(-1),
-                    "d_gen": -d_fake.detach().view(-1), "generated": generated}
+            return out
+        if self.d_cut is not None:
+            raise RuntimeError("d_cut needs the stacked D-step (batched spectral norm, no concurrent_d)")
         if self.concurrent_d:
             generated, d_true, d_fake, d_aug = self._d_forwards_concurrent(latent, real, aug)
         else:

@@ -287,6 +287,10 @@ CONV_CASES = [
     ("conv", 260, 64, 3, 1, 1, 2, 8, 8),      # ragged K = 2340, split count capped at 64: trailing splits own no stage
     ("convT", 296, 64, 4, 2, 1, 2, 4, 4),     # adjoint phases with K = 1184 = Kpad exactly (no padding rows before the tail)
     ("conv", 128, 128, 1, 1, 0, 4, 8, 8),     # K = Kpad = 128: 8 stages, the split threshold
+    # tall 192 x 128 tiles (M a multiple of 192 and >= 128 tiles): adjoint phases and the regular direction
+    ("convT", 192, 192, 4, 2, 1, 16, 16, 16),
+    ("conv", 48, 192, 3, 1, 1, 16, 32, 32),
+    ("convT", 384, 192, 1, 1, 0, 8, 32, 32),  # 1x1 transposed, M = 192 (dgrad direction runs with M = 384: two tall tiles)
 ]
 
 
