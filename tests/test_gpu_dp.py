@@ -63,7 +63,7 @@ def _oracle_shard_means(z, world=2):
             pen = O.consistency_penalty(d_true, O.discriminator_forward(PD, aug, cfg))
             (d_error + pen).backward()
         d_grads.append({k: g.clone() for k, g in O._grads_of(PD).items()})
-        losses.append(float(d_error))
+        losses.append(float(d_error.detach()))
         states.append((PG, PD))
     d_mean = mean(d_grads)
     g_grads = []
