@@ -429,6 +429,12 @@ def gen_size256():
     _gen_step_record("g13_256_narrow", 256, 2, 1)
 
 
+def gen_size256_full():
+    """G20: BASELINE.json configs[4]'s architecture AS NAMED - 256x256 at FULL width (G 225.9 M / D 186.5 M parameters,
+    ConvTranspose [3072, 3072, 4, 4], self-attention over N = 65 536 positions at C = 48) - at batch 2, fp32."""
+    _gen_step_record("g20_256_full", 256, 2, 8)
+
+
 def gen_variants():
     """G15-G19: the architecture switches of libs/config.py that the shipped defaults leave off:
     DEPTH > 1 (conv.py:61-67), FEATURE_MULTIPLIER > 1 (conv.py:16,21), SEPARABLE (conv.py:17, attention.py:15-21)."""
@@ -472,7 +478,7 @@ def _gen_step_record(name, S, B, ff, **consts):
 
 
 GROUPS = {"ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
-          "config2": gen_config2, "size256": gen_size256, "variants": gen_variants}
+          "config2": gen_config2, "size256": gen_size256, "size256_full": gen_size256_full, "variants": gen_variants}
 
 
 def main(argv):
@@ -480,7 +486,7 @@ def main(argv):
         GROUPS[argv[1]]()
         return
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {})]
+    runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {}), ("size256_full", {})]
     runs += [("init", {"LOCATE_GOLDEN_INIT_CFG": c}) for c in ("tiny32", "full32", "full64")]
     runs += [("variants", {"LOCATE_GOLDEN_VARIANT": v}) for v in VARIANTS]
     for name, extra in runs:

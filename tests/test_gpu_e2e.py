@@ -116,6 +116,8 @@ def test_tiny_two_steps_golden(batched_sn, concurrent_d, stacked_d, overlap_wgra
     ("g14_config2_64", 64, 64, 8, True, {}),      # configs[1]: the benchmark workload itself, from the reference
     ("g12_config3_128", 128, 2, 8, True, {}),     # configs[3]: the reference's default 128x128 architecture (C up to 1536)
     ("g13_256_narrow", 256, 2, 1, True, {}),      # configs[4]'s 256x256 architecture at 1/8 width (attention over N = 65 536)
+    ("g20_256_full", 256, 2, 8, True, {}),        # configs[4]'s architecture at FULL width: G 225.9 M / D 186.5 M parameters,
+                                                  # ConvTranspose [3072, 3072, 4, 4], N = 65 536 softmax rows at C = 48
     # the libs/config.py switches the shipped defaults leave off
     ("g15_depth2_32", 32, 4, 2, True, dict(depth=2)),
     ("g16_depth3_fm2_32", 32, 4, 2, False, dict(depth=3, feature_multiplier=2)),
