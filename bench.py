@@ -44,21 +44,45 @@ def parse():
     return ap.parse_args()
 
 
+PMC_RECORD = os.path.join(ROOT, "profiles", "r02_conv_pmc_mem.json")
+
+
+def _pmc_traffic(flops_by_stage):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc record (tools/pmc_summary.py --json
+    over tools/roofline_stages.py: the same four launches, FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes) - reported only while the record's SHA-256 of conv.hip matches the source this run uses.
+    Counters need the profiler, so this is the one figure of the line that is not measured live."""
+    import hashlib
+    try:
+        rec = json.load(open(PMC_RECORD))
+        src = os.path.join(ROOT, "locate_amd", "csrc", "conv.hip")
+        if rec.get("conv_hip_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
+            return None, "stale: conv.hip changed since %s was taken" % os.path.relpath(PMC_RECORD, ROOT)
+        stages = rec["stages"]
+        if len(stages) != len(flops_by_stage):
+            return None, "record has %d stages, this run %d" % (len(stages), len(flops_by_stage))
+        tot = sum(flops_by_stage)
+        return sum(st["hbm_bytes_per_launch"] * f for st, f in zip(stages, flops_by_stage)) / tot, os.path.relpath(PMC_RECORD, ROOT)
+    except (OSError, ValueError, KeyError) as e:
+        return None, "no PMC record (%s)" % type(e).__name__
+
+
 def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     """Dominant kernel: the implicit GEMM behind the generator's four C>=96 ConvTranspose 4x4 s2 stages (75 % of
     the step's FLOPs).  Algorithmic FLOPs per launch
     = 2 * B * (2H * 2W) * C_out * C_in * 4 taps (each output pixel of a 4x4 s2 p1 transposed conv has 2x2 taps);
+    algorithmic bytes per launch = weights + input + output once each, fp32 (4 (16 C^2 + B C H W + B C 2H 2W));
     time = HIP events on the launch stream around `reps` launches of each stage's forward.
-    The kernel computes fp32-faithful products on the bf16 matrix cores: both operands split exactly into three
-    bf16 pieces, six v_mfma_f32_32x32x16_bf16 per slice.  Its roof is therefore the dense bf16
-    MFMA peak divided by the six instructions each algorithmic multiply-add costs: 2500 / 6 = 416.7 TFLOP/s
-    (for comparison the fp32-input MFMA peaks at 157.3 TFLOP/s)."""
+    fp32 line: the kernel computes fp32-faithful products on the bf16 matrix cores - both operands split exactly into three
+    bf16 pieces, six v_mfma_f32_32x32x16_bf16 per slice - so its roof is the dense bf16 MFMA peak
+    divided by the six instructions each algorithmic multiply-add costs: 2500 / 6 = 416.7 TFLOP/s (the fp32-input MFMA
+    peaks at 157.3).  bf16 line: one MFMA per slice, roof 2500."""
     from locate_amd import ops
     from locate_amd.models import generator_features
     feats = generator_features(cfg)
     rt = ops.Runtime()
     rt.precision = 1 if bf16 else 0
-    total_flops, total_ms, rows = 0.0, 0.0, []
+    total_flops, total_ms, rows, flops_list, alg_bytes = 0.0, 0.0, [], [], 0.0
     size = 2
     for i in range(len(feats) - 1):
         c = feats[i]
@@ -80,25 +104,111 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
                 e1.synchronize()
             ms = e0.elapsed_time(e1) / reps
             flops = 2.0 * batch * (2 * size) * (2 * size) * c * c * 4
+            nbytes = 4.0 * (16 * c * c + batch * c * size * size + batch * c * 4 * size * size)
             rows.append({"C": c, "in": size, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2)})
             total_flops += flops
             total_ms += ms
+            flops_list.append(flops)
+            alg_bytes += nbytes * flops
         size *= 2
     achieved = total_flops / total_ms / 1e9 if total_ms > 0 else 0.0
-    if bf16:
-        return {"bound": "mfma", "kernel": "conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 "
-                                           "slice, fp32 accumulate, ConvTranspose 4x4 s2 fwd)",
-                "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-                "traffic": None, "per_stage": rows}
-    peak = round(2500.0 / 6.0, 1)
-    return {"bound": "mfma", "kernel": "conv_igemm_bx6_kernel (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per "
-                                       "32x32x16 slice, ConvTranspose 4x4 s2 fwd)",
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            # HBM-side bytes per launch, mean of the four stages: 2 * FETCH_SIZE + WRITE_SIZE from separate rocprofv3
-            # --pmc passes over the same launches (profiles/r01_conv_pmc_mem.txt; FETCH_SIZE doubled per
-            # MI355X_MICROARCH.md).  Measured offline (PMC needs the profiler), not in this run.
-            "traffic": 1.68e8, "algorithmic_bytes": 7.1e7, "executed_bf16_mfma_tflops": round(6 * achieved, 1), "bf16_dense_peak": 2500.0,
-            "fp32_mfma_peak": 157.3, "per_stage": rows}
+    alg_bytes = alg_bytes / total_flops if total_flops else 0.0          # FLOP-weighted mean per launch, like `traffic`
+    traffic, source = (None, "not collected for the bf16 variant") if bf16 else _pmc_traffic(flops_list)
+    peak = 2500.0 if bf16 else round(2500.0 / 6.0, 1)
+    out = {"bound": "mfma",
+           "kernel": ("conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 slice, fp32 accumulate, "
+                      "ConvTranspose 4x4 s2 fwd)") if bf16 else
+                     ("conv_igemm_bx6_kernel (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per 32x32x16 slice, "
+                      "ConvTranspose 4x4 s2 fwd)"),
+           "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           "traffic": None if traffic is None else round(traffic), "traffic_source": source,
+           "algorithmic_bytes": round(alg_bytes), "per_stage": rows}
+    if not bf16:
+        out.update({"executed_bf16_mfma_tflops": round(6 * achieved, 1), "bf16_dense_peak": 2500.0, "fp32_mfma_peak": 157.3})
+    return out
+
+
+def hbm_bound_block(batch, dev, reps=10):
+    """north_star's ">= 40 % achieved HBM bandwidth" figure: the HBM-bound kernels of the step (RootTanh, InPlaceNorm incl. its
+    statistics pass, residual gate, softmax over positions, bilinear upsample, average pool, FeaturePooling), forward and
+    backward, at the activation shapes config 2 actually runs them on, each weighted by how often the step runs it; timed live
+    with HIP events through the C ABI.  Algorithmic bytes = every distinct operand read or written once, fp32 (DESIGN.md
+    section 4.2); achieved = sum of bytes / sum of time; peak 8.0 TB/s (MI355X_MICROARCH.md; ~6.3 TB/s is what a copy reaches)."""
+    from locate_amd._lib import check, lib
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def P(t):
+        return t.data_ptr()
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    rows, tot_b, tot_t = [], 0.0, 0.0
+
+    def add(name, shape, count, nbytes, fn):
+        nonlocal tot_b, tot_t
+        t = timed(fn)
+        rows.append({"op": name, "shape": "x".join(map(str, shape)), "per_step": count, "GBps": round(nbytes / t / 1e9, 1)})
+        tot_b += count * nbytes
+        tot_t += count * t
+
+    # (shape, how many RootTanh fwd / bwd, norm fwd / bwd, gate fwd / bwd per step run on it) - generator stages of config 2;
+    # the step runs the generator forward twice and its backward once
+    for shape, n_act, n_norm, n_gate in (((batch, 96, 64, 64), 1, 0, 0), ((batch, 48, 64, 64), 3, 3, 3), ((batch, 96, 32, 32), 1, 1, 1),
+                                         ((batch, 192, 32, 32), 1, 0, 0), ((batch, 192, 16, 16), 2, 3, 3)):
+        Bn, C, H, W = shape
+        hw, planes, n = H * W, Bn * C, Bn * C * H * W
+        x, g, y, gx, a = (torch.randn(shape, device=dev) for _ in range(5))
+        add("RootTanh fwd", shape, 2 * n_act, 8 * n, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, st)))
+        add("RootTanh bwd", shape, n_act, 12 * n, lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, st)))
+        if n_norm:
+            w_, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            dw, db, stats = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(2, device=dev)
+            ws_f = torch.empty(max(L.locate_norm_stats_workspace_bytes(), 16), dtype=torch.uint8, device=dev)
+            ws_b = torch.empty(max(L.locate_norm_bwd_workspace_bytes(Bn, C), 16), dtype=torch.uint8, device=dev)
+            add("InPlaceNorm fwd (stats + apply)", shape, 2 * n_norm, 12 * n,
+                lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), st)))
+            add("InPlaceNorm bwd", shape, n_norm, 20 * n,
+                lambda: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w_), 0, P(b_), 0, P(gx), P(dw), P(db), Bn, C, hw, 1, P(ws_b), st)))
+        if n_gate:
+            da = torch.empty_like(a)
+            gam, dgam = torch.full((1,), 2.0, device=dev), torch.empty(1, device=dev)
+            ws_g = torch.empty(max(L.locate_gate_bwd_workspace_bytes(planes), 16), dtype=torch.uint8, device=dev)
+            add("gate fwd", shape, 2 * n_gate, 12 * n, lambda: check(L.locate_gate_fwd(P(x), P(a), 0, P(gam), P(y), planes, hw, st)))
+            add("gate bwd", shape, n_gate, 20 * n,
+                lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), st)))
+        if (C, H) in ((48, 64), (192, 16)):
+            add("softmax over H*W fwd", shape, 2, 8 * n, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)))
+            add("softmax over H*W bwd", shape, 1, 12 * n, lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)))
+        if H == 32 and C == 96:
+            hp = torch.empty(Bn, C // 2, H, W, device=dev)
+            up = torch.empty(Bn, C // 2, 2 * H, 2 * W, device=dev)
+            gup = torch.randn_like(up)
+            add("FeaturePooling / 2", shape, 2, 6 * n, lambda: check(L.locate_feature_pool_fwd(P(x), P(hp), n // 2, 2, st)))
+            add("upsample x2 fwd", (Bn, C // 2, H, W), 2, 10 * n, lambda: check(L.locate_upsample2x_fwd(P(hp), P(up), planes // 2, H, W, st)))
+            add("upsample x2 bwd", (Bn, C // 2, H, W), 1, 10 * n, lambda: check(L.locate_upsample2x_bwd(P(gup), P(hp), planes // 2, H, W, st)))
+    # discriminator side: the stacked [3B] pass at 32x32 (stem output) - average pool and its gate / norm
+    shape = (3 * batch, 32, 32, 32)
+    Bn, C, H, W = shape
+    n, planes = Bn * C * H * W, Bn * C
+    x, gx = torch.randn(shape, device=dev), torch.empty(shape, device=dev)
+    q = torch.empty(Bn, C, H // 2, W // 2, device=dev)
+    gq = torch.randn_like(q)
+    add("avgpool 2x2 fwd", shape, 1, 5 * n, lambda: check(L.locate_avgpool2_fwd(P(x), P(q), planes, H, W, st)))
+    add("avgpool 2x2 bwd", shape, 1, 5 * n, lambda: check(L.locate_avgpool2_bwd(P(gq), P(gx), planes, H, W, st)))
+    achieved = tot_b / tot_t / 1e9 if tot_t > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+            "what": "byte-weighted over the step's HBM-bound kernels (element-wise, norm, gate, softmax, resampling) at config 2's "
+                    "activation shapes and multiplicities; algorithmic fp32 bytes, HIP events, this run", "kernels": rows}
 
 
 def cpu_baseline(cfg, batch, steps):
@@ -122,8 +232,10 @@ def cpu_baseline(cfg, batch, steps):
         O.train_step(PG, PD, G.noise.clone(), og, od, latent, real, aug, ocfg)
     dt = (time.time() - t0) / steps
     return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d warm-up + %d timed G+D steps of the same workload (%dx%d, batch %d, fp32) with the CPU oracle"
-                      % (1, steps, S, S, batch), "s_per_step": round(dt, 3)}
+            "sample": "%d warm-up + %d timed G+D steps of the same workload (%dx%d, batch %d, fp32) with this repo's CPU oracle - a port "
+                      "of the reference's step pinned to it by tests/golden, NOT the reference itself (which cannot travel to the GPU "
+                      "box; its own figure, 13.5 images/sec on 8 threads, is in BASELINE.md)" % (1, steps, S, S, batch),
+            "s_per_step": round(dt, 3)}
 
 
 def main():
@@ -238,8 +350,9 @@ def main():
             "dtype": "f32 (contractions: exact 3 x bf16 operand splits on the bf16 MFMA, fp32 accumulate)" if args.dtype == "fp32" else
                      "bf16 (contraction operands rounded to bf16, one MFMA per slice, fp32 accumulate; storage, statistics, "
                      "sigma, activations and Nadam fp32) - NOT the headline line, see --dtype fp32", "data": "synthetic",
-            "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (BASELINE.json configs[1]), "
-                                   "self/feature attention at 16x16 and 64x64, random-init weights" % (S, S, B),
+            "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (%s of BASELINE.json configs[1]: 64x64 RGB bs 64), "
+                                   "self/feature attention at 16x16 and 64x64, random-init weights"
+                                   % (S, S, B, "the fp32 variant - the reference's own precision -" if args.dtype == "fp32" else "the bf16 variant"),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" + ("" if args.no_overlap else ", G-step generator pass on a second stream")
                                   + (" + bucketed RCCL all-reduce on a side stream between the graphs of the segmented backward" if world > 1 else ""))
@@ -249,6 +362,8 @@ def main():
         if comm is not None:
             line["data_parallel"] = comm
         line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
+        if S == 64:
+            line["hbm_bound"] = hbm_bound_block(B, dev)
         if S == 64:
             # step-level figures with SURVEY.md section 8(d)'s op-by-op accounting of the REFERENCE graph (7.5 GFLOP and
             # 356 MB fp32 per image at 64x64): effective rates - fusion that never materialises an intermediate counts
