@@ -118,7 +118,8 @@ __device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx
             if (a.mode == 0) {
                 if (col < a.M) {
                     const int c = k / T, t = k - c * T;
-                    v = a.w[((int64_t)col * a.C + c) * T + t];
+                    const int th = t / a.TW, tw = t - th * a.TW;
+                    v = a.w[(((int64_t)col * a.C + c) * a.KH + a.kh0 + th) * a.KW + a.kw0 + tw];
                 }
             } else {
                 if (col < a.C) {
@@ -265,7 +266,7 @@ static PackJob make_pack_job(const PackBatch& b, int nphase) {
     PackJob j;
     j.batch = b; j.nphase = nphase; j.block_start = 0; j.pad = 0;
     const PackArgs& a0 = b.ph[0];
-    if (a0.mode == 0 && nphase == 1) {
+    if (a0.mode == 0 && nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW) {
         j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS) {
         j.kind = 1; j.gx = (a0.ld + 255) / 256; j.gy = a0.M + 1;
@@ -1209,6 +1210,33 @@ static size_t slab_floats(const IgParams& p, int nmax) {
     return a > b ? a : b;
 }
 
+// Taps that can ever meet the input.  On the deepest maps most of a kernel only ever sees padding (a 5x5 s2 p2 conv that
+// maps 2x2 -> 1x1 reads 4 of its 25 taps, a 3x3 p1 conv on a 1x1 map one of 9): the contraction then runs over the bounding
+// range of useful taps only - fewer K rows to stream, pack and multiply - with identical results (the dropped taps
+// contribute exact zeros).
+//   regular direction: tap k reads input i = o*s - pad + k for outputs o in [0, out): useful iff some i lands in [0, in)
+static void useful_taps(int in, int out, int k, int s, int pad, int* lo, int* n) {
+    int first = -1, last = -1;
+    for (int t = 0; t < k; ++t) {
+        bool any = false;
+        for (int o = 0; o < out && !any; ++o) {
+            const int i = o * s - pad + t;
+            any = i >= 0 && i < in;
+        }
+        if (any) { if (first < 0) first = t; last = t; }
+    }
+    if (first < 0) { first = 0; last = 0; }          // nothing useful: keep one tap (it reads zeros)
+    *lo = first; *n = last - first + 1;
+}
+//   adjoint phase: tap th reads the gathered map at q + d0 - th for phase rows q in [0, Q): useful iff that lands in [0, out)
+static void useful_phase_taps(int Q, int out, int d0, int T, int* lo, int* n) {
+    int first = T > 0 ? d0 - out + 1 : 0, last = d0 + Q - 1;
+    if (first < 0) first = 0;
+    if (last > T - 1) last = T - 1;
+    if (first > last) { first = 0; last = 0; }
+    *lo = first; *n = last - first + 1;
+}
+
 static void phase_taps(int parity, int pad, int K, int s, int* k0, int* d0, int* T) {
     *k0 = (parity + pad) % s;
     *d0 = (parity + pad - *k0) / s;
@@ -1253,14 +1281,16 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         PackArgs pa;
         pa.w = w; pa.out = panel;
         pa.M = g.M; pa.C = g.C; pa.KH = g.KH; pa.KW = g.KW; pa.mode = 0;
-        pa.kh0 = pa.kw0 = 0; pa.s = 1; pa.TH = g.KH; pa.TW = g.KW;
-        pa.K = g.C * g.KH * g.KW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
-        pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = -g.pad_h; pa.dys = 1; pa.dx0 = -g.pad_w; pa.dxs = 1;
+        pa.s = 1;
+        useful_taps(g.H, g.OH, g.KH, g.stride, g.pad_h, &pa.kh0, &pa.TH);
+        useful_taps(g.W, g.OW, g.KW, g.stride, g.pad_w, &pa.kw0, &pa.TW);
+        pa.K = g.C * pa.TH * pa.TW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
+        pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = pa.kh0 - g.pad_h; pa.dys = 1; pa.dx0 = pa.kw0 - g.pad_w; pa.dxs = 1;
         pa.dmin = tap_dmin(pa);
         batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
-        ph.T = g.KH * g.KW;
+        ph.T = pa.TH * pa.TW;
         ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
         off = panel_floats(pa.rows, pa.ld);
         nmax = g.B * g.OH * g.OW;
@@ -1275,6 +1305,13 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 const int QH = py < g.H ? (g.H - py + g.stride - 1) / g.stride : 0;
                 const int QW = px < g.W ? (g.W - px + g.stride - 1) / g.stride : 0;
                 if (QH == 0 || QW == 0) continue;
+                {
+                    int lo, n;
+                    useful_phase_taps(QH, g.OH, dy0, TH, &lo, &n);
+                    kh0 += g.stride * lo; dy0 -= lo; TH = TH > 0 ? n : 0;
+                    useful_phase_taps(QW, g.OW, dx0, TW, &lo, &n);
+                    kw0 += g.stride * lo; dx0 -= lo; TW = TW > 0 ? n : 0;
+                }
                 IgPhase& ph = p.ph[p.nphase++];
                 PackArgs pa;
                 pa.w = w; pa.out = panel ? panel + off : nullptr;

@@ -49,15 +49,14 @@ def test_bf16_contraction_vs_fp32_reference(kind, cin, cout, k, s, p, B, H, W):
     rt = ops.Runtime()
     rt.precision = 1
     wg, xg = w.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
-    u, v = torch.randn(wshape[0], device=DEV), torch.randn(w.numel() // wshape[0], device=DEV)
+    # u = v = 0: the rank-1 spectral-norm term dsigma u v^T of dW_bar vanishes, what is left is the contraction's own G / sigma
+    u, v = torch.zeros(wshape[0], device=DEV), torch.zeros(w.numel() // wshape[0], device=DEV)
     sigma, wv = torch.tensor([1.0, 1.0], device=DEV), torch.zeros(wshape[0], device=DEV)
     y = ops.SNConvFn.apply(xg, wg, u, v, None, sigma, wv, ops.ConvSpec(kind, k, k, s, p, p), rt)
     y.backward(g.to(DEV))
     assert_close(y.detach().cpu(), yr.detach(), 8e-3, "bf16 y")
     assert_close(xg.grad.cpu(), xr.grad, 8e-3, "bf16 dx")
-    # dW_bar = G / sigma + dsigma u v^T with dsigma = -<G, W> / sigma^2: remove the rank-1 term to compare the contraction
-    gw = wg.grad.cpu() + float((wr.grad * w).sum()) * torch.outer(u.cpu(), v.cpu()).view_as(w)
-    assert_close(gw, wr.grad, 2e-2, "bf16 dw")
+    assert_close(wg.grad.cpu(), wr.grad, 8e-3, "bf16 dw")
     # and it IS a different arithmetic: the fp32-faithful path is ~1000x closer
     y32 = ops.SNConvFn.apply(xg.detach(), wg.detach(), u, v, None, sigma, wv, ops.ConvSpec(kind, k, k, s, p, p))
     e32 = float((y32.cpu() - yr.detach()).abs().max() / yr.detach().abs().max())

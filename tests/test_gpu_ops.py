@@ -287,6 +287,12 @@ CONV_CASES = [
     ("conv", 260, 64, 3, 1, 1, 2, 8, 8),      # ragged K = 2340, split count capped at 64: trailing splits own no stage
     ("convT", 296, 64, 4, 2, 1, 2, 4, 4),     # adjoint phases with K = 1184 = Kpad exactly (no padding rows before the tail)
     ("conv", 128, 128, 1, 1, 0, 4, 8, 8),     # K = Kpad = 128: 8 stages, the split threshold
+    # maps so small that most taps only ever see padding (the contraction runs over the useful taps only)
+    ("conv", 64, 64, 5, 2, 2, 6, 2, 2),       # 2x2 -> 1x1: 4 of 25 taps (the discriminator's last block)
+    ("conv", 32, 48, 3, 1, 1, 5, 1, 1),       # 3x3 p1 on a 1x1 map: the centre tap only (the discriminator's head)
+    ("conv", 16, 16, 5, 2, 2, 3, 3, 3),       # 3x3 -> 2x2: 4 of 5 rows / columns
+    ("convT", 32, 32, 4, 2, 1, 3, 1, 1),      # transposed 1x1 -> 2x2: one tap per sub-pixel phase
+    ("conv", 8, 8, 5, 2, 2, 2, 1, 5),         # 1 x 5 map: one useful row, all five columns
     # tall 192 x 128 tiles (M a multiple of 192 and >= 128 tiles): adjoint phases and the regular direction
     ("convT", 192, 192, 4, 2, 1, 16, 16, 16),
     ("conv", 48, 192, 3, 1, 1, 16, 32, 32),
