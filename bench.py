@@ -176,7 +176,7 @@ def hbm_bound_block(batch, dev, reps=10):
             ws_f = torch.empty(max(L.locate_norm_stats_workspace_bytes(), 16), dtype=torch.uint8, device=dev)
             ws_b = torch.empty(max(L.locate_norm_bwd_workspace_bytes(Bn, C), 16), dtype=torch.uint8, device=dev)
             add("InPlaceNorm fwd (stats + apply)", shape, 2 * n_norm, 12 * n,
-                lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), st)))
+                lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), None, st)))
             add("InPlaceNorm bwd", shape, n_norm, 20 * n,
                 lambda: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w_), 0, P(b_), 0, P(gx), P(dw), P(db), Bn, C, hw, 1, P(ws_b), st)))
         if n_gate:

@@ -32,6 +32,10 @@ int locate_device_info(char* arch_name, int name_len, int* cu_count, int* wave_s
 int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
 /* generator output tanh (libs/models.py:66); backward takes the forward OUTPUT y */
+/* style chain link (libs/block.py:119-125): out[r, :z] = latent[r, :], out[r, z:] = RootTanh(pre[r, :]) in one launch, and
+ * its backward on the gradient's column slice in place (row stride in elements) */
+int locate_act_cat_rows_fwd(const float* latent, const float* pre, float* out, int rows, int z, int w, void* stream);
+int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, float* gpre, int rows, int w, void* stream);
 int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream);
 
@@ -44,8 +48,11 @@ int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, 
  * with RootTanh, libs/conv.py:22-24).  groups > 1: the batch stacks `groups` independent forward calls of B/groups
  * samples each (the three discriminator passes of main.py:149-152), every one with its OWN mean/std.
  * stats_out = groups x {mean, std}; workspace: locate_norm_stats_workspace_bytes() */
+/* pre_partial (nullable): statistics partials of x already produced by the kernel that wrote x (locate_gate_fwd_stats with
+ * the same group count); the statistics pass over x is then skipped */
 int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out, int with_act,
-                    float* stats_out, int B, int C, int hw, int groups, void* workspace, void* stream);
+                    float* stats_out, int B, int C, int hw, int groups, void* workspace, const double* pre_partial,
+                    void* stream);
 size_t locate_norm_bwd_workspace_bytes(int B, int C);
 /* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward); with_act = 1: g is the
  * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out;
@@ -61,6 +68,11 @@ int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t
  *      a_per_plane = 1: `a` holds one value per (batch, channel) plane (stride-0 expand, libs/util_modules.py:6-12) */
 int locate_gate_fwd(const float* x, const float* a, int a_per_plane, const float* gamma, float* out, int64_t planes, int hw,
                     void* stream);
+/* the same gate plus, from its epilogue, the InPlaceNorm statistics partials (sum, sum of squares per block, fp64) of `out`
+ * for `groups` calls stacked along the batch: stats_partial = locate_norm_stats_workspace_bytes() bytes, handed to
+ * locate_norm_fwd as pre_partial (libs/block.py:44-52: a gate's output is what the next norm normalises) */
+int locate_gate_fwd_stats(const float* x, const float* a, int a_per_plane, const float* gamma, float* out, int64_t planes,
+                          int hw, int groups, double* stats_partial, void* stream);
 size_t locate_gate_bwd_workspace_bytes(int64_t planes);
 int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g, float* dx, float* da,
                     float* dgamma, int64_t planes, int hw, void* workspace, void* stream);

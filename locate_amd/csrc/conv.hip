@@ -1063,8 +1063,10 @@ static void launch_pointwise(const IgParams& p, hipStream_t st) {
 static int pick_bm(int M);
 static int igemm_bm(int M, int nmax, int nphase) {
     if (M % 192 == 0 && M >= 192 && !path_disabled("tall") && !path_disabled("bx6")) {
+        // only where the tall tiling alone fills its two blocks per CU (512 slots): with split-K on top, or on launches of a
+        // hundred-odd blocks, the 128-row tiles at three blocks per CU measured faster (profiles/r02_igemm_tiles.txt)
         const long long tiles = (long long)((nmax + 127) / 128) * (M / 192) * nphase;
-        if (tiles >= 128) return 192;
+        if (tiles >= 512) return 192;
     }
     return pick_bm(M);
 }

@@ -74,6 +74,45 @@ LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, i
     return LOCATE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Style chain link (libs/block.py:119-125): the next style linear sees cat([latent, RootTanh(pre)], dim = 1).  One launch
+// writes that concatenation - out[r, :z] = latent[r, :], out[r, z:] = RootTanh(pre[r, :]) - instead of an activation
+// launch plus two copy launches; the backward takes the gradient's column slice in place (row stride = z + w).
+// The tensors are tiny ([batch, <= 1000]); one thread per output element.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) act_cat_rows_kernel(const float* __restrict__ latent, const float* __restrict__ pre,
+                                                           float* __restrict__ out, int rows, int z, int w) {
+    const int total = rows * (z + w);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / (z + w), c = i - r * (z + w);
+        out[i] = c < z ? latent[r * z + c] : roottanh_f(pre[r * w + (c - z)]);
+    }
+}
+
+// gpre[r, j] = g[r * g_rs + j] * RootTanh'(pre[r, j])
+__global__ void __launch_bounds__(256) act_rows_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ g, int g_rs,
+                                                           float* __restrict__ gpre, int rows, int w) {
+    const int total = rows * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / w, j = i - r * w;
+        gpre[i] = roottanh_grad_f(pre[i], g[(int64_t)r * g_rs + j]);
+    }
+}
+
+LOCATE_API int locate_act_cat_rows_fwd(const float* latent, const float* pre, float* out, int rows, int z, int w, void* stream) {
+    LOCATE_REQUIRE(latent && pre && out && rows > 0 && z >= 0 && w > 0 && (int64_t)rows * (z + w) < (1ll << 31), "locate_act_cat_rows_fwd: bad arguments");
+    act_cat_rows_kernel<<<stream_grid((int64_t)rows * (z + w), 256), 256, 0, as_stream(stream)>>>(latent, pre, out, rows, z, w);
+    LOCATE_LAUNCH_CHECK("locate_act_cat_rows_fwd");
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, float* gpre, int rows, int w, void* stream) {
+    LOCATE_REQUIRE(pre && g && gpre && rows > 0 && w > 0 && g_row_stride >= w && g_row_stride < (1ll << 31), "locate_act_rows_bwd: bad arguments");
+    act_rows_bwd_kernel<<<stream_grid((int64_t)rows * w, 256), 256, 0, as_stream(stream)>>>(pre, g, (int)g_row_stride, gpre, rows, w);
+    LOCATE_LAUNCH_CHECK("locate_act_rows_bwd");
+    return LOCATE_OK;
+}
+
 LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_tanh_fwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
@@ -117,6 +156,54 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float av = a_per_plane ? a[dhw.div((unsigned)i)] : a[i];
         out[i] = fmaf(gm, av, 1.0f) * x[i];
+    }
+}
+
+// The same gate, and - in the epilogue of the kernel that produces the tensor - the partial sums (sum, sum of squares, fp64,
+// fixed order) of the InPlaceNorm that almost always consumes a gate's output next (libs/block.py:44-52: every block output
+// is a gate output, every block / attention branch starts with a norm).  Layout = stats_partial_kernel's (norm.hip):
+// blockIdx.y = group of stacked calls, partial[group][2 * gridDim.x]; the norm then skips its own statistics pass - one
+// full read of the tensor and one launch less.
+__global__ void __launch_bounds__(256) gate_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                             const float* __restrict__ gamma, float* __restrict__ out,
+                                                             int64_t n_group, int hw, int a_per_plane,
+                                                             double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    const float gm = gamma[0];
+    const int64_t g0 = (int64_t)blockIdx.y * n_group;
+    x += g0; out += g0;
+    if (!a_per_plane) a += g0;
+    partial += (int64_t)blockIdx.y * 2 * gridDim.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0.0, q = 0.0;
+    if (!a_per_plane && (n_group & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n_group >> 2); i += stride) {
+            float4 xv = x4[i], av = a4[i], o;
+            o.x = fmaf(gm, av.x, 1.0f) * xv.x; o.y = fmaf(gm, av.y, 1.0f) * xv.y;
+            o.z = fmaf(gm, av.z, 1.0f) * xv.z; o.w = fmaf(gm, av.w, 1.0f) * xv.w;
+            o4[i] = o;
+            const double a_ = o.x, b_ = o.y, c_ = o.z, d_ = o.w;
+            s += (a_ + b_) + (c_ + d_);
+            q += (a_ * a_ + b_ * b_) + (c_ * c_ + d_ * d_);
+        }
+    } else {
+        const DivU32 dhw((unsigned)hw);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_group; i += stride) {
+            const float av = a_per_plane ? a[dhw.div((unsigned)(g0 + i))] : a[i];
+            const float o = fmaf(gm, av, 1.0f) * x[i];
+            out[i] = o;
+            s += (double)o;
+            q += (double)o * (double)o;
+        }
+    }
+    s = block_sum<double>(s, scratch);
+    q = block_sum<double>(q, scratch);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = q;
     }
 }
 
@@ -211,9 +298,26 @@ LOCATE_API int locate_gate_fwd(const float* x, const float* a, int a_per_plane, 
     return LOCATE_OK;
 }
 
+// out = (gamma a + 1) x AND the InPlaceNorm statistics partials of `out` for `groups` stacked calls:
+// stats_partial = locate_norm_stats_workspace_bytes() bytes, to be handed to locate_norm_fwd as `pre_partial`.
+LOCATE_API int locate_gate_fwd_stats(const float* x, const float* a, int a_per_plane, const float* gamma, float* out,
+                                     int64_t planes, int hw, int groups, double* stats_partial, void* stream) {
+    LOCATE_REQUIRE(planes > 0 && hw > 0 && planes * hw < (1ll << 31) && stats_partial, "locate_gate_fwd_stats: bad arguments");
+    LOCATE_REQUIRE(groups >= 1 && groups <= 4 && planes % groups == 0, "locate_gate_fwd_stats: bad group count");
+    const int64_t n_g = planes / groups * hw;
+    LOCATE_REQUIRE(n_g > 1 && (groups == 1 || (n_g & 3) == 0), "locate_gate_fwd_stats: group size must be a multiple of 4");
+    int np = stream_grid(n_g, 256 * 16);          // the SAME partial count locate_norm_fwd derives from the group size
+    if (np > 512) np = 512;
+    gate_fwd_stats_kernel<<<dim3(np, groups), 256, 0, as_stream(stream)>>>(x, a, gamma, out, n_g, hw, a_per_plane, stats_partial);
+    LOCATE_LAUNCH_CHECK("locate_gate_fwd_stats");
+    return LOCATE_OK;
+}
+
 LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { (void)planes; return 4096 * sizeof(double); }
 
 // da: [planes*hw] when a_per_plane == 0, [planes] otherwise.  dgamma: one float (overwritten).
+// (Tried and dropped: the kernel's last-arriving block reducing dgamma itself instead of the second launch - up to 4096
+// blocks taking a ticket from ONE counter serialise at ~90 arrivals per microsecond: +0.7 ms per training step.)
 LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g,
                                float* dx, float* da, float* dgamma, int64_t planes, int hw, void* workspace,
                                void* stream) {

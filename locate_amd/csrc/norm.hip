@@ -146,10 +146,12 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
 // out = (x - mean(x)) * scale / std(x) + bias  (with_act = 0), or RootTanh of it (with_act = 1; the plain value is not
 // stored - backward recomputes it).  B = groups * (B / groups); statistics per group; stats_out: [groups][2].
 // scale: [C] (scale_per_sample = 0) or [B*C].  Two launches.
+// pre_partial (nullable): the statistics partials of x already produced by the kernel that wrote x (locate_gate_fwd_stats,
+// same group count) - the statistics pass is then skipped.
 LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out,
                                int with_act, float* stats_out, int B, int C, int hw, int groups, void* workspace,
-                               void* stream) {
-    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace && stats_out && out, "locate_norm_fwd: bad arguments");
+                               const double* pre_partial, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && (workspace || pre_partial) && stats_out && out, "locate_norm_fwd: bad arguments");
     LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_fwd: bad group count %d for batch %d", groups, B);
     LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_fwd: x must be 16-byte aligned");
     const int64_t planes_g = (int64_t)(B / groups) * C, n_g = planes_g * hw;
@@ -157,10 +159,13 @@ LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per
     LOCATE_REQUIRE(groups == 1 || (n_g & 3) == 0, "locate_norm_fwd: grouped tensors need a group size that is a multiple of 4");
     int np = stream_grid(n_g, 256 * 16);
     if (np > NORM_MAX_PARTIALS) np = NORM_MAX_PARTIALS;
-    double* partial = static_cast<double*>(workspace);
+    const double* partial = pre_partial;
     hipStream_t st = as_stream(stream);
-    stats_partial_kernel<<<dim3(np, groups), 256, 0, st>>>(x, n_g, partial);
-    LOCATE_LAUNCH_CHECK("locate_norm_fwd(stats)");
+    if (partial == nullptr) {
+        stats_partial_kernel<<<dim3(np, groups), 256, 0, st>>>(x, n_g, static_cast<double*>(workspace));
+        LOCATE_LAUNCH_CHECK("locate_norm_fwd(stats)");
+        partial = static_cast<const double*>(workspace);
+    }
     const dim3 grid(stream_grid(n_g, 1024), groups);
     if (with_act)
         norm_apply_fused_kernel<true><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw);

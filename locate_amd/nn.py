@@ -188,7 +188,7 @@ class CatModule(_TwoBranch):
         return ops.cat_channels(*self._run(function_input, layer_input, scale))
 
 
-class ResModule(_TwoBranch):
+class ResModule(_TwoBranch, _Bound):
     """out = (gamma * layer(x) + 1) * skip(x) with one scalar gamma, initialised to (+-1) + m + 1 (the sign is the
     orthogonal initialisation of a 1 x 1 matrix: one RNG draw; libs/merge.py:46-62)."""
 
@@ -201,7 +201,7 @@ class ResModule(_TwoBranch):
     def forward(self, function_input, layer_input=None, scale=None):
         skip, branch = self._run(function_input, layer_input, scale)
         compact = getattr(branch, "_locate_compact", None)     # un-expanded [B, C, 1, 1] source (see Expand)
-        return ops.residual_gate(skip, branch if compact is None else compact, self.gamma)
+        return ops.residual_gate(skip, branch if compact is None else compact, self.gamma, self.runtime)
 
 
 class FeaturePooling(nn.Module):
@@ -370,6 +370,10 @@ class LinearModule(nn.Module):
         out = self.module(function_input)
         return self.nlin(out), out
 
+    def pre_activation(self, function_input):
+        """The linear alone; the activation is left to the consumer (BlockBlock fuses it with the next link's concatenation)."""
+        return self.module(function_input)
+
 
 class Block(nn.Module):
     """One up / down stage (libs/block.py:15-52): a gated conv branch over the resampled skip branch and, on attention
@@ -433,8 +437,10 @@ class BlockBlock(nn.Module):
         scales = []
         start = self.first_style[stage]
         for linear in self.mul_blocks[start:start + len(self.plan[stage].style)]:
-            carry, pre = linear(latent if carry is None else ops.cat_channels(latent, carry))
+            # `carry` is the previous link's PRE-activation: RootTanh and the concatenation with the latent are one launch
+            pre = linear.pre_activation(latent if carry is None else ops.act_cat(latent, carry))
             scales.append(pre.view(*pre.shape, 1, 1))
+            carry = pre
         return scales, carry
 
     def forward(self, function_input, noise=None):

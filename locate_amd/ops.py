@@ -77,8 +77,37 @@ class TanhFn(torch.autograd.Function):
         return gx
 
 
+class ActCatFn(torch.autograd.Function):
+    """cat([latent, RootTanh(pre)], dim=1) for [B, z] / [B, w] matrices in ONE launch - a style-chain link
+    (libs/block.py:119-125: the next style linear sees the latent next to the previous link's activated output)."""
+
+    @staticmethod
+    def forward(ctx, latent, pre):
+        latent, pre = _c(latent, "style latent"), _c(pre, "style pre-activation")
+        rows, z = latent.shape
+        w = pre.shape[1]
+        out = torch.empty(rows, z + w, dtype=torch.float32, device=pre.device)
+        check(lib().locate_act_cat_rows_fwd(_p(latent), _p(pre), _p(out), rows, z, w, _stream()), "locate_act_cat_rows_fwd")
+        ctx.save_for_backward(pre)
+        ctx.z = z
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pre, = ctx.saved_tensors
+        g = _chk(g, "style chain gradient")
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        z = ctx.z
+        gpre = torch.empty_like(pre)
+        check(lib().locate_act_rows_bwd(_p(pre), g.data_ptr() + 4 * z, g.stride(0), _p(gpre), pre.shape[0], pre.shape[1], _stream()),
+              "locate_act_rows_bwd")
+        return (g[:, :z] if ctx.needs_input_grad[0] else None), gpre
+
+
 root_tanh = RootTanhFn.apply
 tanh = TanhFn.apply
+act_cat = ActCatFn.apply
 
 
 # ------------------------------------------------------------------------------------------------
@@ -171,7 +200,9 @@ class Runtime:
         self._dv_layers = {}
         if not layers:
             return
-        key = tuple((w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["scratch"].data_ptr()) for _, u, w, _, _, st in layers)
+        # every field a record holds: equal keys mean byte-identical tables, whatever objects the addresses belonged to before
+        key = tuple((w.data_ptr(), u.data_ptr(), st["dv"].data_ptr(), st["dsig"].data_ptr(), st["scratch"].data_ptr(), h, wd)
+                    for _, u, w, h, wd, st in layers)
         tab = self._dv_tables.get(key)
         if tab is None:
             rec = struct.Struct("<8Q4i")
@@ -256,7 +287,7 @@ class InPlaceNormFn(torch.autograd.Function):
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
-    def forward(ctx, x, scale, bias, with_act, groups):
+    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None):
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
@@ -269,10 +300,10 @@ class InPlaceNormFn(torch.autograd.Function):
         L = lib()
         st = _stream()
         stats = torch.empty(2 * groups, dtype=torch.float32, device=x.device)
-        ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device)
+        ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device) if pre_partial is None else None
         out = torch.empty_like(x)       # RootTanh(norm(x)) when with_act, else norm(x)
         check(L.locate_norm_fwd(_p(x), _p(scale_c), int(per_sample), _p(bias_c), _p(out), int(bool(with_act)), _p(stats), B, C, hw,
-                                groups, _p(ws), st), "locate_norm_fwd")
+                                groups, _p(ws), _p(pre_partial), st), "locate_norm_fwd")
         ctx.per_sample, ctx.with_act, ctx.groups = per_sample, bool(with_act), groups
         ctx.scale_shape, ctx.bias_shape = scale.shape, bias.shape
         ctx.save_for_backward(x, scale_c, bias_c, stats)
@@ -292,11 +323,15 @@ class InPlaceNormFn(torch.autograd.Function):
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
                                 _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), st), "locate_norm_bwd")
-        return dx, dscale, dbias, None, None
+        return dx, dscale, dbias, None, None, None
 
 
 def inplace_norm(x, scale, bias, with_act=False, runtime=None):
-    return InPlaceNormFn.apply(x, scale, bias, with_act, (runtime or DEFAULT_RUNTIME).stacked)
+    groups = (runtime or DEFAULT_RUNTIME).stacked
+    # statistics partials left by the gate kernel that produced x (residual_gate): usable if taken for the same grouping
+    pre = getattr(x, "_locate_stats", None)
+    pre_partial = pre[0] if (pre is not None and pre[1] == groups and x.is_contiguous()) else None
+    return InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -306,7 +341,7 @@ class GateFn(torch.autograd.Function):
     """out = (gamma * a + 1) * x;  `a` has x's shape or is [B, C, 1, 1] (one value per plane)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma):
+    def forward(ctx, x, a, gamma, stats_groups=0, holder=None):
         x = _c(x, "gate input")
         a = _c(a, "gate attention")
         gamma = _c(gamma, "gate gamma")
@@ -316,7 +351,15 @@ class GateFn(torch.autograd.Function):
         if not per_plane and a.numel() != x.numel():
             raise ValueError("gate: attention shape %s does not match input %s" % (tuple(a.shape), tuple(x.shape)))
         out = torch.empty_like(x)
-        check(lib().locate_gate_fwd(_p(x), _p(a), int(per_plane), _p(gamma), _p(out), planes, hw, _stream()), "locate_gate_fwd")
+        L = lib()
+        n_g = x.numel() // stats_groups if stats_groups else 0
+        if stats_groups and x.shape[0] % stats_groups == 0 and n_g > 1 and (stats_groups == 1 or n_g % 4 == 0):
+            partial = torch.empty(L.locate_norm_stats_workspace_bytes() // 8, dtype=torch.float64, device=x.device)
+            check(L.locate_gate_fwd_stats(_p(x), _p(a), int(per_plane), _p(gamma), _p(out), planes, hw, stats_groups, _p(partial),
+                                          _stream()), "locate_gate_fwd_stats")
+            holder.append((partial, stats_groups))
+        else:
+            check(L.locate_gate_fwd(_p(x), _p(a), int(per_plane), _p(gamma), _p(out), planes, hw, _stream()), "locate_gate_fwd")
         ctx.save_for_backward(x, a, gamma)
         ctx.per_plane = per_plane
         return out
@@ -334,10 +377,21 @@ class GateFn(torch.autograd.Function):
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
         check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), _p(dgamma), planes, hw, _p(ws),
                                 _stream()), "locate_gate_bwd")
-        return dx, da, dgamma
+        return dx, da, dgamma, None, None
 
 
-residual_gate = GateFn.apply
+def residual_gate(x, a, gamma, runtime=None, with_stats=True):
+    """out = (gamma a + 1) x.  with_stats: the kernel also leaves the InPlaceNorm statistics partials of `out` (for the
+    runtime's current stacked-call grouping) on the result, so that a norm consuming it skips its own statistics pass."""
+    if not with_stats:
+        return GateFn.apply(x, a, gamma)
+    holder = []
+    out = GateFn.apply(x, a, gamma, (runtime or DEFAULT_RUNTIME).stacked, holder)
+    if holder:
+        out._locate_stats = holder[0]
+    return out
+
+
 
 
 # ------------------------------------------------------------------------------------------------

@@ -293,10 +293,10 @@ CONV_CASES = [
     ("conv", 16, 16, 5, 2, 2, 3, 3, 3),       # 3x3 -> 2x2: 4 of 5 rows / columns
     ("convT", 32, 32, 4, 2, 1, 3, 1, 1),      # transposed 1x1 -> 2x2: one tap per sub-pixel phase
     ("conv", 8, 8, 5, 2, 2, 2, 1, 5),         # 1 x 5 map: one useful row, all five columns
-    # tall 192 x 128 tiles (M a multiple of 192 and >= 128 tiles): adjoint phases and the regular direction
-    ("convT", 192, 192, 4, 2, 1, 16, 16, 16),
-    ("conv", 48, 192, 3, 1, 1, 16, 32, 32),
-    ("convT", 384, 192, 1, 1, 0, 8, 32, 32),  # 1x1 transposed, M = 192 (dgrad direction runs with M = 384: two tall tiles)
+    # tall 192 x 128 tiles (M a multiple of 192 and >= 512 tiles): adjoint phases and the regular direction
+    ("convT", 192, 192, 4, 2, 1, 64, 16, 16),
+    ("conv", 48, 192, 3, 1, 1, 64, 32, 32),
+    ("convT", 384, 192, 1, 1, 0, 64, 32, 32), # 1x1 transposed, M = 192 (dgrad direction runs with M = 384: two tall tiles)
 ]
 
 

@@ -59,7 +59,7 @@ def main():
         ws_b = torch.empty(max(L.locate_norm_bwd_workspace_bytes(Bn, C), 16), dtype=torch.uint8, device=dev)
         for act in (0, 1):
             report("InPlaceNorm" + (" + RootTanh" if act else ""), shape,
-                   lambda act=act: check(L.locate_norm_fwd(P(x), P(w), 0, P(b), P(y), act, P(stats), Bn, C, hw, 1, P(ws_f), st)),
+                   lambda act=act: check(L.locate_norm_fwd(P(x), P(w), 0, P(b), P(y), act, P(stats), Bn, C, hw, 1, P(ws_f), None, st)),
                    lambda act=act: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w), 0, P(b), act, P(gx), P(dw), P(db), Bn, C, hw, 1,
                                                            P(ws_b), st)), 3 * n, 5 * n)    # statistics pass + apply | plane sums + dx
         a = torch.randn(shape, device=dev)
