@@ -1218,6 +1218,7 @@ static size_t slab_floats(const IgParams& p, int nmax) {
 // contribute exact zeros).
 //   regular direction: tap k reads input i = o*s - pad + k for outputs o in [0, out): useful iff some i lands in [0, in)
 static void useful_taps(int in, int out, int k, int s, int pad, int* lo, int* n) {
+    if (path_disabled("taps")) { *lo = 0; *n = k; return; }
     int first = -1, last = -1;
     for (int t = 0; t < k; ++t) {
         bool any = false;
@@ -1232,6 +1233,7 @@ static void useful_taps(int in, int out, int k, int s, int pad, int* lo, int* n)
 }
 //   adjoint phase: tap th reads the gathered map at q + d0 - th for phase rows q in [0, Q): useful iff that lands in [0, out)
 static void useful_phase_taps(int Q, int out, int d0, int T, int* lo, int* n) {
+    if (path_disabled("taps")) { *lo = 0; *n = T > 0 ? T : 1; return; }
     int first = T > 0 ? d0 - out + 1 : 0, last = d0 + Q - 1;
     if (first < 0) first = 0;
     if (last > T - 1) last = T - 1;
