@@ -34,6 +34,9 @@ def parse():
                          "slice, fp32 accumulation and storage (BASELINE configs[1] as named; tolerances in tests/test_gpu_bf16.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-only", action="store_true",
+                    help="profiling runs: time the step only - no roofline / hbm_bound / cpu_baseline blocks (their launches would "
+                         "mix into a rocprofv3 trace of the step)")
     ap.add_argument("--concurrent-d", action="store_true",
                     help="run the three discriminator passes of the D-step on three streams (measured: no gain under "
                          "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
@@ -361,9 +364,10 @@ def main():
         }
         if comm is not None:
             line["data_parallel"] = comm
-        line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
-        if S == 64:
-            line["hbm_bound"] = hbm_bound_block(B, dev)
+        if not args.step_only:
+            line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
+            if S == 64:
+                line["hbm_bound"] = hbm_bound_block(B, dev)
         if S == 64:
             # step-level figures with SURVEY.md section 8(d)'s op-by-op accounting of the REFERENCE graph (7.5 GFLOP and
             # 356 MB fp32 per image at 64x64): effective rates - fusion that never materialises an intermediate counts
@@ -371,7 +375,7 @@ def main():
             line["step_level"] = {"algorithmic_tflops": round(7.5e9 * B / step_s / 1e12, 2),
                                   "reference_graph_GBps": round(356e6 * B / step_s / 1e9, 1),
                                   "frac_of_hbm_peak": round(356e6 * B / step_s / 8.0e12, 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.step_only:
             line["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
