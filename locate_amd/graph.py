@@ -14,6 +14,14 @@ import torch
 
 
 class GraphedTrainStep:
+    """SIDE EFFECT OF CONSTRUCTION: `max(warmup, 2)` REAL training iterations are run eagerly on the sample batch before the
+    capture - lazily created state (optimizer moments and device tables, spectral-norm tables, arrival counters) must exist,
+    and the discriminator's u / v must already be trainable (reference main.py:172) so that the captured iteration has the
+    steady-state autograd structure.  Weights, u / v and the Nadam states therefore ADVANCE by that many steps; wrapping a
+    run that is already in progress adds them on one batch (pass that run's own current batch).  The capture itself
+    executes nothing.  After replays, use the networks eagerly as usual: replay() bumps the parameters' version counters so
+    that weight panels are re-packed."""
+
     def __init__(self, step, latent, real, aug, warmup=2, overlap=None):
         """overlap (default: on for minibatches == 1 without the three-stream D-step): the iteration is captured as SIX
         graphs - D-step generator pass | D forward/backward | D Nadam | G-step generator pass | D(fake) + backward | G
