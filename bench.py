@@ -172,7 +172,7 @@ def hbm_bound_block(batch, dev, reps=10):
         hw, planes, n = H * W, Bn * C, Bn * C * H * W
         x, g, y, gx, a = (torch.randn(shape, device=dev) for _ in range(5))
         add("RootTanh fwd", shape, 2 * n_act, 8 * n, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, st)))
-        add("RootTanh bwd", shape, n_act, 12 * n, lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, st)))
+        add("RootTanh bwd", shape, n_act, 12 * n, lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, st)))
         if n_norm:
             w_, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
             dw, db, stats = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(2, device=dev)
@@ -181,14 +181,14 @@ def hbm_bound_block(batch, dev, reps=10):
             add("InPlaceNorm fwd (stats + apply)", shape, 2 * n_norm, 12 * n,
                 lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), None, st)))
             add("InPlaceNorm bwd", shape, n_norm, 20 * n,
-                lambda: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w_), 0, P(b_), 0, P(gx), P(dw), P(db), Bn, C, hw, 1, P(ws_b), st)))
+                lambda: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w_), 0, P(b_), 0, P(gx), P(dw), P(db), Bn, C, hw, 1, P(ws_b), 0, st)))
         if n_gate:
             da = torch.empty_like(a)
             gam, dgam = torch.full((1,), 2.0, device=dev), torch.empty(1, device=dev)
             ws_g = torch.empty(max(L.locate_gate_bwd_workspace_bytes(planes), 16), dtype=torch.uint8, device=dev)
             add("gate fwd", shape, 2 * n_gate, 12 * n, lambda: check(L.locate_gate_fwd(P(x), P(a), 0, P(gam), P(y), planes, hw, st)))
             add("gate bwd", shape, n_gate, 20 * n,
-                lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), st)))
+                lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, st)))
         if (C, H) in ((48, 64), (192, 16)):
             add("softmax over H*W fwd", shape, 2, 8 * n, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)))
             add("softmax over H*W bwd", shape, 1, 12 * n, lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)))
@@ -207,7 +207,7 @@ def hbm_bound_block(batch, dev, reps=10):
     q = torch.empty(Bn, C, H // 2, W // 2, device=dev)
     gq = torch.randn_like(q)
     add("avgpool 2x2 fwd", shape, 1, 5 * n, lambda: check(L.locate_avgpool2_fwd(P(x), P(q), planes, H, W, st)))
-    add("avgpool 2x2 bwd", shape, 1, 5 * n, lambda: check(L.locate_avgpool2_bwd(P(gq), P(gx), planes, H, W, st)))
+    add("avgpool 2x2 bwd", shape, 1, 5 * n, lambda: check(L.locate_avgpool2_bwd(P(gq), P(gx), planes, H, W, 0, st)))
     achieved = tot_b / tot_t / 1e9 if tot_t > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
             "what": "byte-weighted over the step's HBM-bound kernels (element-wise, norm, gate, softmax, resampling) at config 2's "

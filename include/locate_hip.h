@@ -30,7 +30,7 @@ int locate_device_info(char* arch_name, int name_len, int* cu_count, int* wave_s
 
 /* ---- RootTanh: y = (x^2+1)^(1/4) tanh x and its hand-written derivative (libs/activation.py:7-36) ---- */
 int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream);
-int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
+int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* stream);   /* accumulate: gx += */
 /* generator output tanh (libs/models.py:66); backward takes the forward OUTPUT y */
 /* style chain link (libs/block.py:119-125): out[r, :z] = latent[r, :], out[r, z:] = RootTanh(pre[r, :]) in one launch, and
  * its backward on the gradient's column slice in place (row stride in elements) */
@@ -57,9 +57,11 @@ size_t locate_norm_bwd_workspace_bytes(int B, int C);
 /* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward); with_act = 1: g is the
  * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out;
  * dscale / dbias sum over all groups (the reference accumulates the three passes' gradients, main.py:153-157) */
+/* accumulate_dx / accumulate (locate_norm_bwd, locate_gate_bwd, locate_feature_pool_bwd): add into the output instead of
+ * overwriting it - the second consumer of a forked tensor completes the gradient the first one started (ops.fork) */
 int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample,
                     const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw, int groups,
-                    void* workspace, void* stream);
+                    void* workspace, int accumulate_dx, void* stream);
 /* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
 size_t locate_channel_sum_workspace_bytes(int B, int C, int hw);
 int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* workspace, void* stream);
@@ -75,7 +77,8 @@ int locate_gate_fwd_stats(const float* x, const float* a, int a_per_plane, const
                           int hw, int groups, double* stats_partial, void* stream);
 size_t locate_gate_bwd_workspace_bytes(int64_t planes);
 int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g, float* dx, float* da,
-                    float* dgamma, int64_t planes, int hw, void* workspace, void* stream);
+                    float* dgamma, int64_t planes, int hw, void* workspace, int accumulate_dx,
+                    void* stream);
 
 /* ---- softmax over the last dimension of [rows, n] (libs/attention.py:35,47) ---- */
 int locate_softmax_fwd(const float* x, float* y, int64_t rows, int n, void* stream);
@@ -85,9 +88,9 @@ int locate_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows,
 int locate_upsample2x_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);   /* bilinear, align_corners=False */
 int locate_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream); /* H, W: forward input size */
 int locate_avgpool2_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);
-int locate_avgpool2_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream);   /* H, W: forward input size */
+int locate_avgpool2_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int accumulate, void* stream);   /* H, W: forward input size */
 int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, int r, void* stream);         /* mean of r adjacent flat elements */
-int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, void* stream);
+int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, int accumulate, void* stream);
 /* dst[b, c, :] (+)= src[b, c, :], c < C, independent batch strides (torch.cat along channels and its backward) */
 int locate_copy_channels(const float* src, float* dst, int B, int C, int hw, int64_t src_batch_stride,
                          int64_t dst_batch_stride, int accumulate, void* stream);

@@ -28,7 +28,7 @@ PROTOTYPES = {
     "locate_abi_version": (c_i, []),
     "locate_device_info": (c_i, [ctypes.c_char_p, c_i, c_ip, c_ip]),
     "locate_roottanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
-    "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
+    "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "locate_act_cat_rows_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "locate_act_rows_bwd": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, c_p]),
     "locate_tanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
@@ -37,21 +37,21 @@ PROTOTYPES = {
     "locate_norm_stats": (c_i, [c_p, c_i64, c_p, c_p, c_p]),
     "locate_norm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
     "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
-    "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "locate_channel_sum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "locate_channel_sum": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_p, c_p]),
     "locate_gate_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "locate_gate_fwd_stats": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "locate_gate_bwd_workspace_bytes": (c_sz, [c_i64]),
-    "locate_gate_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    "locate_gate_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),
     "locate_softmax_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_p]),
     "locate_softmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "locate_upsample2x_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "locate_upsample2x_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "locate_avgpool2_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
-    "locate_avgpool2_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "locate_avgpool2_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "locate_feature_pool_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_p]),
-    "locate_feature_pool_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_p]),
+    "locate_feature_pool_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "locate_copy_channels": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, c_i, c_p]),
     "locate_sn_workspace_bytes": (c_sz, [c_i, c_i]),
     "locate_sn_power_iter": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),

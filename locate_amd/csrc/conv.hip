@@ -1031,6 +1031,97 @@ static bool path_disabled(const char* name) {
 static constexpr bool path_disabled(const char*) { return false; }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Contractions on 1x1 maps (the style linears, the squeeze convs of the channel gates, the discriminator's head: a batch of
+// 64 ... 192 rows times a [C, M] matrix, <= 0.1 GFLOP) - 45 launches per step that the tile machinery above runs in
+// 8 ... 25 us each: one or two 128-wide tiles, a dozen dependent memory round trips of prologue, K loop, split-K combine and
+// staged store, for microseconds' worth of arithmetic.  They get a direct form in plain fp32 FMAs (exact fp32 products):
+//   out[n][j] = scale(n) * sum_r in[n][r] * P[r][j] + bias[j]
+// lane = output column j (the K-major fp32 panel row P[r][.] is one coalesced load), the activations in[n][r] are
+// wave-uniform and come through the scalar cache, the eight waves of a block take interleaved 32-row chunks of the reduction
+// and their partial sums are added in wave order through LDS (deterministic).  Forward (adjoint-0 panel: r = c, j = m) and
+// input gradient (adjoint-1 panel: r = m, j = c) are the same kernel.
+// ---------------------------------------------------------------------------------------------
+#define SK_NT 4           // batch rows per block
+#define SK_RC 32          // reduction rows per wave and chunk
+#define SK_WAVES 8        // waves per block: they take interleaved chunks of the reduction
+
+__global__ void __launch_bounds__(64 * SK_WAVES) skinny_rows_kernel(const IgParams p) {
+    const IgPhase& ph = p.ph[0];
+    const int R = ph.K, J = p.M, N = p.B, ld = ph.ld;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int j = blockIdx.x * 64 + lane;
+    const int n0 = blockIdx.y * SK_NT;
+    const bool jok = j < ld;                                   // panel columns J .. ld - 1 are zero
+    const float* __restrict__ P = ph.wp + (jok ? j : 0);
+    const float* __restrict__ in = p.in;
+    float acc[SK_NT];
+#pragma unroll
+    for (int t = 0; t < SK_NT; ++t) acc[t] = 0.0f;
+    const int nchunk = (R + SK_RC - 1) / SK_RC;               // rows up to round_up(R, 32) - 1 exist in the panel (zero beyond R)
+    float cur[SK_RC], nxt[SK_RC];
+    if (wid < nchunk) {
+#pragma unroll
+        for (int i = 0; i < SK_RC; ++i) cur[i] = P[(long long)(wid * SK_RC + i) * ld];
+    }
+    for (int c = wid; c < nchunk; c += SK_WAVES) {
+        const int r0 = c * SK_RC;
+        if (c + SK_WAVES < nchunk) {
+#pragma unroll
+            for (int i = 0; i < SK_RC; ++i) nxt[i] = P[(long long)(r0 + SK_WAVES * SK_RC + i) * ld];
+        }
+        if (r0 + SK_RC <= R) {
+#pragma unroll
+            for (int t = 0; t < SK_NT; ++t) {
+                if (n0 + t < N) {
+                    const float* __restrict__ xr = in + (long long)(n0 + t) * p.in_bs + r0;       // wave-uniform: scalar loads
+#pragma unroll
+                    for (int i = 0; i < SK_RC; ++i) acc[t] = fmaf(xr[i], cur[i], acc[t]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SK_NT; ++t) {
+                if (n0 + t < N) {
+                    const float* __restrict__ xr = in + (long long)(n0 + t) * p.in_bs + r0;
+#pragma unroll
+                    for (int i = 0; i < SK_RC; ++i) {
+                        const float xv = r0 + i < R ? xr[i] : 0.0f;      // never read past the row (the last row ends the tensor)
+                        acc[t] = fmaf(xv, cur[i], acc[t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SK_RC; ++i) cur[i] = nxt[i];
+    }
+    __shared__ float red[SK_WAVES][SK_NT][64];
+#pragma unroll
+    for (int t = 0; t < SK_NT; ++t) red[wid][t][lane] = acc[t];
+    __syncthreads();
+    // wave t finishes row t of the tile: the partial sums in wave order, then scale and bias
+    if (wid < SK_NT) {
+        const int n = n0 + wid;
+        if (n < N && j < J) {
+            float s = red[0][wid][lane];
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) s += red[w][wid][lane];
+            const float sc = p.scale ? p.scale[(p.scale_bg ? n / p.scale_bg : 0) * p.scale_stride] : 1.0f;
+            p.out[(long long)n * p.out_bs + j] = fmaf(s, sc, p.bias ? p.bias[j] : 0.0f);
+        }
+    }
+}
+
+static bool skinny_ok(const IgParams& p) {
+    if (p.nphase != 1 || path_disabled("skinny")) return false;
+    const IgPhase& ph = p.ph[0];
+    return ph.T == 1 && p.H == 1 && p.W == 1 && p.OH == 1 && p.OW == 1 && ph.dy0 == 0 && ph.dx0 == 0 && ph.K >= 1;
+}
+
+static void launch_skinny(const IgParams& p, hipStream_t st) {
+    skinny_rows_kernel<<<dim3((p.M + 63) / 64, (p.B + SK_NT - 1) / SK_NT), 64 * SK_WAVES, 0, st>>>(p);
+}
+
 static bool pointwise_ok(const IgParams& p) {
     if (p.nphase != 1 || path_disabled("pointwise")) return false;
     const IgPhase& ph = p.ph[0];
@@ -1135,6 +1226,12 @@ static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counter
 }
 
 static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who) {
+    if (skinny_ok(p)) {
+        p.ksplit = 1;
+        launch_skinny(p, st);
+        LOCATE_LAUNCH_CHECK(who);
+        return LOCATE_OK;
+    }
     if (pointwise_ok(p)) {
         p.ksplit = 1;
         launch_pointwise(p, st);
@@ -1207,6 +1304,7 @@ static ConvGeom make_geom(const int* g) {
 
 // geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
 static size_t slab_floats(const IgParams& p, int nmax) {
+    if (skinny_ok(p)) return 0;
     // the caller may or may not pass counters: room for whichever form the launch then takes
     const size_t a = igemm_split_plan(p, nmax, false).slab_floats, b = igemm_split_plan(p, nmax, true).slab_floats;
     return a > b ? a : b;
@@ -1945,8 +2043,78 @@ static int wgrad_reduce_grid(int64_t n, int nsplit) {
     return g > 2048 ? 2048 : g;
 }
 
+// Weight gradient of the same 1x1-map layers (skinny_rows_kernel): gw[m][c] = inv_scale * sum_n gy[n][m] x[n][c], an outer-product
+// sum over the 64 ... 192 batch rows.  lane = c (x[n][.] is one coalesced load), a block owns eight rows m (gy[n][m .. m + 7] is
+// wave-uniform: one scalar load) and its four waves a quarter of the batch each, plain fp32 FMAs, no slab; one partial of
+// <unscaled gw, W_bar> per block.
+#define SKW_MT 8          // gradient rows per block
+#define SKW_NC 32         // batch rows per load batch
+
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
+                                                           long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
+                                                           const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
+                                                           double* __restrict__ partial, int N, int M, int C) {
+    __shared__ double scratch[16];
+    __shared__ float red[4][SKW_MT][64];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int j = blockIdx.x * 64 + lane;
+    const int i0 = blockIdx.y * SKW_MT;
+    const bool jok = j < C;
+    const float* __restrict__ xc = x + (jok ? j : 0);
+    float acc[SKW_MT];
+#pragma unroll
+    for (int t = 0; t < SKW_MT; ++t) acc[t] = 0.0f;
+    // the four waves take a quarter of the batch rows each; their partial sums are added in wave order below
+    const int nq = (N + 3) / 4, nlo = wid * nq, nhi = nlo + nq < N ? nlo + nq : N;
+    for (int nb = nlo; nb < nhi; nb += SKW_NC) {
+        float xv[SKW_NC];
+#pragma unroll
+        for (int q = 0; q < SKW_NC; ++q) xv[q] = (jok && nb + q < nhi) ? xc[(long long)(nb + q) * x_bs] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < SKW_NC; ++q) {
+            if (nb + q < nhi) {
+                const float* __restrict__ g = gy + (long long)(nb + q) * gy_bs + i0;          // wave-uniform: scalar loads
+                const float s = scale_bg ? inv_scale[((nb + q) / scale_bg) * scale_stride] : 1.0f;
+                if (i0 + SKW_MT <= M) {
+#pragma unroll
+                    for (int t = 0; t < SKW_MT; ++t) acc[t] = fmaf(g[t] * s, xv[q], acc[t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < SKW_MT; ++t) acc[t] = fmaf((i0 + t < M ? g[t] : 0.0f) * s, xv[q], acc[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SKW_MT; ++t) red[wid][t][lane] = acc[t];
+    __syncthreads();
+    const float sc = (!scale_bg && inv_scale) ? inv_scale[0] : 1.0f;
+    double dot = 0.0;
+#pragma unroll
+    for (int q = 0; q < SKW_MT / 4; ++q) {          // wave w finishes rows 2w, 2w + 1
+        const int t = wid * (SKW_MT / 4) + q;
+        if (jok && i0 + t < M) {
+            const float v = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
+            const long long o = (long long)(i0 + t) * C + j;
+            if (w_ref) dot += (double)v * (double)w_ref[o];
+            gw[o] = v * sc;
+        }
+    }
+    if (partial) {
+        dot = block_sum<double>(dot, scratch);
+        if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = dot;
+    }
+}
+
+static bool skinny_wgrad_ok(const ConvGeom& g) {
+    return !path_disabled("skinny") && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad_h == 0 && g.pad_w == 0 && g.H == 1 &&
+           g.W == 1 && g.OH == 1 && g.OW == 1;
+}
+static dim3 skinny_wgrad_grid(const ConvGeom& g) { return dim3((g.C + 63) / 64, (g.M + SKW_MT - 1) / SKW_MT); }
+
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
     const ConvGeom g = make_geom(geom);
+    if (skinny_wgrad_ok(g)) return 0;
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
     return nsplit > 1 ? (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float) : 0;
@@ -1955,6 +2123,10 @@ LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
 // number of doubles written to `inner_partial` by locate_conv_wgrad for this geometry
 LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
     const ConvGeom g = make_geom(geom);
+    if (skinny_wgrad_ok(g)) {
+        const dim3 grid = skinny_wgrad_grid(g);
+        return (int)(grid.x * grid.y);
+    }
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
     return nsplit > 1 ? wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW, nsplit) : tiles;
@@ -1976,6 +2148,12 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
                    g.B / scale_group_batch <= 4 && !w_ref && !inner_partial)), "locate_conv_wgrad: bad group scaling arguments");
     hipStream_t st = as_stream(stream);
+    if (skinny_wgrad_ok(g)) {          // 1x1 maps: plain fp32 FMAs at either precision setting (see skinny_rows_kernel)
+        skinny_wgrad_kernel<<<skinny_wgrad_grid(g), 256, 0, st>>>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_group_batch, scale_stride,
+                                                                  inner_partial, g.B, g.M, g.C);
+        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(1x1 map)");
+        return LOCATE_OK;
+    }
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
     LOCATE_REQUIRE(nsplit == 1 || workspace, "locate_conv_wgrad: split reduction needs a workspace");

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) unary_fwd_kernel(const float* __restrict_
 // OP 0: gx = g * roottanh'(a) with a = forward INPUT.   OP 1: gx = g * (1 - a^2) with a = forward OUTPUT.
 template <int OP>
 __global__ void __launch_bounds__(256) unary_bwd_kernel(const float* __restrict__ a, const float* __restrict__ g,
-                                                        float* __restrict__ gx, int64_t n) {
+                                                        float* __restrict__ gx, int64_t n, int accumulate) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -50,10 +50,16 @@ __global__ void __launch_bounds__(256) unary_bwd_kernel(const float* __restrict_
             o.x = w.x * (1.0f - v.x * v.x); o.y = w.y * (1.0f - v.y * v.y);
             o.z = w.z * (1.0f - v.z * v.z); o.w = w.w * (1.0f - v.w * v.w);
         }
+        if (accumulate) {
+            const float4 c = o4[i];
+            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
         o4[i] = o;
     }
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        gx[i] = OP == 0 ? roottanh_grad_f(a[i], g[i]) : g[i] * (1.0f - a[i] * a[i]);
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float o = OP == 0 ? roottanh_grad_f(a[i], g[i]) : g[i] * (1.0f - a[i] * a[i]);
+        gx[i] = accumulate ? gx[i] + o : o;
+    }
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -66,10 +72,11 @@ LOCATE_API int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* st
     return LOCATE_OK;
 }
 
-LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream) {
+// accumulate != 0: gx += ... (the second backward kernel of a forked tensor, see ops.fork)
+LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(gy) && aligned16(gx), "locate_roottanh_bwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_bwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, gy, gx, n);
+    unary_bwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, gy, gx, n, accumulate);
     LOCATE_LAUNCH_CHECK("locate_roottanh_bwd");
     return LOCATE_OK;
 }
@@ -124,7 +131,7 @@ LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream
 LOCATE_API int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(y) && aligned16(gy) && aligned16(gx), "locate_tanh_bwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_bwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(y, gy, gx, n);
+    unary_bwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(y, gy, gx, n, 0);
     LOCATE_LAUNCH_CHECK("locate_tanh_bwd");
     return LOCATE_OK;
 }
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ g,
                                                              float* __restrict__ dx, float* __restrict__ da_full,
                                                              float* __restrict__ da_plane, double* __restrict__ block_x2g,
-                                                             int64_t planes, int hw, int a_per_plane) {
+                                                             int64_t planes, int hw, int a_per_plane, int accumulate_dx) {
     __shared__ double wsum[4], px2g[4];
     __shared__ float pxg[4];
     double wacc = 0.0;
@@ -237,8 +244,13 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                 float4 av = make_float4(ap, ap, ap, ap);
                 if (!a_per_plane) av = reinterpret_cast<const float4*>(a + base)[i];
                 const float4 xg = make_float4(xv.x * gv.x, xv.y * gv.y, xv.z * gv.z, xv.w * gv.w);
-                reinterpret_cast<float4*>(dx + base)[i] = make_float4(fmaf(gm, av.x, 1.0f) * gv.x, fmaf(gm, av.y, 1.0f) * gv.y,
-                                                                      fmaf(gm, av.z, 1.0f) * gv.z, fmaf(gm, av.w, 1.0f) * gv.w);
+                float4 o = make_float4(fmaf(gm, av.x, 1.0f) * gv.x, fmaf(gm, av.y, 1.0f) * gv.y, fmaf(gm, av.z, 1.0f) * gv.z,
+                                       fmaf(gm, av.w, 1.0f) * gv.w);
+                if (accumulate_dx) {
+                    const float4 old = reinterpret_cast<const float4*>(dx + base)[i];
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                reinterpret_cast<float4*>(dx + base)[i] = o;
                 if (!a_per_plane) reinterpret_cast<float4*>(da_full + base)[i] = make_float4(xg.x * gm, xg.y * gm, xg.z * gm, xg.w * gm);
                 sxg += (xg.x + xg.y) + (xg.z + xg.w);
                 sx2g += (xg.x * xv.x + xg.y * xv.y) + (xg.z * xv.z + xg.w * xv.w);
@@ -248,7 +260,8 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                 const float xv = x[base + i], gv = g[base + i];
                 const float av = a_per_plane ? ap : a[base + i];
                 const float xg = xv * gv;
-                dx[base + i] = fmaf(gm, av, 1.0f) * gv;
+                const float o = fmaf(gm, av, 1.0f) * gv;
+                dx[base + i] = accumulate_dx ? dx[base + i] + o : o;
                 if (!a_per_plane) da_full[base + i] = xg * gm;
                 sxg += xg;
                 sx2g = fmaf(xg, xv, sx2g);
@@ -320,7 +333,7 @@ LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { (void)planes
 // blocks taking a ticket from ONE counter serialise at ~90 arrivals per microsecond: +0.7 ms per training step.)
 LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g,
                                float* dx, float* da, float* dgamma, int64_t planes, int hw, void* workspace,
-                               void* stream) {
+                               int accumulate_dx, void* stream) {
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
     double* block_x2g = static_cast<double*>(workspace);
     const bool whole_block = hw >= 1024;
@@ -329,11 +342,11 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
     if (whole_block)
         gate_bwd_plane_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
-                                                                            a_per_plane);
+                                                                            a_per_plane, accumulate_dx);
     else
         gate_bwd_plane_kernel<1><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
-                                                                            a_per_plane);
+                                                                            a_per_plane, accumulate_dx);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
     gate_bwd_final_kernel<<<1, 256, 0, as_stream(stream)>>>(block_x2g, dgamma, (int)blocks);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(final)");

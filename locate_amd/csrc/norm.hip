@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
                                                           const float* __restrict__ stats, const float* __restrict__ scale,
                                                           int scale_per_sample, const float* __restrict__ bias,
                                                           const double* __restrict__ partial, int npartial,
-                                                          float* __restrict__ dx, int64_t planes_g, int C, int hw) {
+                                                          float* __restrict__ dx, int64_t planes_g, int C, int hw, int accumulate) {
     __shared__ float consts[2];
     const int grp = blockIdx.y;
     const float mu = stats[2 * grp], s = stats[2 * grp + 1];
@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
             const float ys = y * inv_s;
             o.x = fmaf(ys, gv.x, fmaf(k, xv.x - mu, -m)); o.y = fmaf(ys, gv.y, fmaf(k, xv.y - mu, -m));
             o.z = fmaf(ys, gv.z, fmaf(k, xv.z - mu, -m)); o.w = fmaf(ys, gv.w, fmaf(k, xv.w - mu, -m));
+            if (accumulate) { const float4 old = o4[i]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
             o4[i] = o;
         }
         return;
@@ -345,7 +346,8 @@ __global__ void __launch_bounds__(256) norm_bwd_dx_kernel(const float* __restric
         const int c = (int)(p % C);
         const float y = scale[scale_per_sample ? p : c];
         const float gv = norm_go<ACT>(x[i], g[i], mu, inv_s, y, ACT ? bias[c] : 0.0f);
-        dx[i] = fmaf(y * inv_s, gv, fmaf(k, x[i] - mu, -m));
+        const float o = fmaf(y * inv_s, gv, fmaf(k, x[i] - mu, -m));
+        dx[i] = accumulate ? dx[i] + o : o;
     }
 }
 
@@ -357,9 +359,12 @@ LOCATE_API size_t locate_norm_bwd_workspace_bytes(int B, int C) {
 // with_act = 1: g is the gradient w.r.t. RootTanh(norm(x)) (the fused forward of locate_norm_fwd); the activation's
 // derivative is applied on the fly from the recomputed norm output, so neither that output nor a separate
 // RootTanh-backward pass exists.
+// accumulate_dx != 0: dx += (the gradient) instead of dx = ...: the tensor x feeds a second consumer whose backward kernel
+// has already written its share into the same buffer (ops.fork in the Python layer) - autograd's separate add launch and
+// its extra pass over the tensor go away.
 LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stats, const float* scale,
                                int scale_per_sample, const float* bias, int with_act, float* dx, float* dscale, float* dbias,
-                               int B, int C, int hw, int groups, void* workspace, void* stream) {
+                               int B, int C, int hw, int groups, void* workspace, int accumulate_dx, void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd: bad shape or missing workspace");
     LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_bwd: bad group count");
     LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd: with_act needs the bias");
@@ -382,9 +387,9 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
     const dim3 grid(stream_grid(planes_g * hw, 1024), groups);
     if (with_act)
-        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw);
+        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw, accumulate_dx);
     else
-        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw);
+        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw, accumulate_dx);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
     return LOCATE_OK;
 }

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restri
 }
 
 __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                           int64_t planes, int H, int W) {
+                                                           int64_t planes, int H, int W, int accumulate) {
     const int OH = H / 2, OW = W / 2;
     const unsigned n = (unsigned)(planes * H * W);
     const unsigned stride = gridDim.x * blockDim.x;
@@ -193,13 +193,14 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restri
         dw.divmod(i, t, ix);
         dh.divmod(t, p, iy);
         const int oy = (int)(iy >> 1), ox = (int)(ix >> 1);
-        gx[i] = (oy < OH && ox < OW) ? gy[(int64_t)p * OH * OW + oy * OW + ox] * 0.25f : 0.0f;
+        const float o = (oy < OH && ox < OW) ? gy[(int64_t)p * OH * OW + oy * OW + ox] * 0.25f : 0.0f;
+        gx[i] = accumulate ? gx[i] + o : o;
     }
 }
 
 // H, W multiples of 2 and W of 4: one thread per four consecutive input-gradient pixels (two pooled values, one 16-byte store)
 __global__ void __launch_bounds__(256) avgpool2_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                               int64_t planes, int H, int W) {
+                                                               int64_t planes, int H, int W, int accumulate) {
     const int OW = W / 2, W4 = W / 4;
     const unsigned n = (unsigned)(planes * H * W4);
     const unsigned stride = gridDim.x * blockDim.x;
@@ -210,7 +211,12 @@ __global__ void __launch_bounds__(256) avgpool2_bwd_vec_kernel(const float* __re
         dh.divmod(t, p, iy);
         const float2 g = *reinterpret_cast<const float2*>(gy + ((int64_t)p * (H / 2) + (iy >> 1)) * OW + 2 * ux);
         const float a = g.x * 0.25f, b = g.y * 0.25f;
-        reinterpret_cast<float4*>(gx)[i] = make_float4(a, a, b, b);
+        float4 o = make_float4(a, a, b, b);
+        if (accumulate) {
+            const float4 c = reinterpret_cast<const float4*>(gx)[i];
+            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
+        reinterpret_cast<float4*>(gx)[i] = o;
     }
 }
 
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256) feature_pool_fwd_kernel(const float* __re
 }
 
 __global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                               int64_t n_out, int r) {
+                                                               int64_t n_out, int r, int accumulate) {
     const unsigned n = (unsigned)(n_out * r);
     const unsigned stride = gridDim.x * blockDim.x;
     const DivU32 dr((unsigned)r);
@@ -236,7 +242,8 @@ __global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __re
     const float inv = 1.0f / (float)r;         // exact for powers of two; other ratios keep the division (same rounding as ATen)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float g = gy[dr.div(i)];
-        gx[i] = pow2 ? g * inv : g / (float)r;
+        const float o = pow2 ? g * inv : g / (float)r;
+        gx[i] = accumulate ? gx[i] + o : o;
     }
 }
 
@@ -271,12 +278,13 @@ LOCATE_API int locate_upsample2x_bwd(const float* a, float* b, int64_t planes, i
 // x: [planes, H, W] -> y: [planes, H/2, W/2]
 RESAMPLE_ENTRY(locate_avgpool2_fwd, avgpool2_fwd_kernel, planes * (H / 2) * (W / 2))
 // gy: [planes, H/2, W/2] -> gx: [planes, H, W]   (H, W are the INPUT sizes of the forward)
-LOCATE_API int locate_avgpool2_bwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
+// accumulate != 0: gx += ... (the second backward kernel of a forked tensor, see ops.fork)
+LOCATE_API int locate_avgpool2_bwd(const float* a, float* b, int64_t planes, int H, int W, int accumulate, void* stream) {
     LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_avgpool2_bwd: bad shape");
     if ((W & 3) == 0 && (H & 1) == 0 && (((uintptr_t)a & 7) | ((uintptr_t)b & 15)) == 0)
-        avgpool2_bwd_vec_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+        avgpool2_bwd_vec_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W, accumulate);
     else
-        avgpool2_bwd_kernel<<<stream_grid(planes * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+        avgpool2_bwd_kernel<<<stream_grid(planes * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W, accumulate);
     LOCATE_LAUNCH_CHECK("locate_avgpool2_bwd");
     return LOCATE_OK;
 }
@@ -288,9 +296,9 @@ LOCATE_API int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, 
     return LOCATE_OK;
 }
 
-LOCATE_API int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, void* stream) {
+LOCATE_API int locate_feature_pool_bwd(const float* gy, float* gx, int64_t n_out, int r, int accumulate, void* stream) {
     LOCATE_REQUIRE(n_out > 0 && r > 0 && n_out * r < (1ll << 31), "locate_feature_pool_bwd: bad shape");
-    feature_pool_bwd_kernel<<<stream_grid(n_out * r, 256), 256, 0, as_stream(stream)>>>(gy, gx, n_out, r);
+    feature_pool_bwd_kernel<<<stream_grid(n_out * r, 256), 256, 0, as_stream(stream)>>>(gy, gx, n_out, r, accumulate);
     LOCATE_LAUNCH_CHECK("locate_feature_pool_bwd");
     return LOCATE_OK;
 }

@@ -43,7 +43,8 @@ def _p(t):
 # ------------------------------------------------------------------------------------------------
 class RootTanhFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
+        ctx.slot = slot
         x = _c(x, "root_tanh input")
         y = torch.empty_like(x)
         check(lib().locate_roottanh_fwd(_p(x), _p(y), x.numel(), _stream()), "locate_roottanh_fwd")
@@ -54,9 +55,9 @@ class RootTanhFn(torch.autograd.Function):
     def backward(ctx, g):
         x, = ctx.saved_tensors
         g = _c(g)
-        gx = torch.empty_like(x)
-        check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), _stream()), "locate_roottanh_bwd")
-        return gx
+        gx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
+        check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), acc, _stream()), "locate_roottanh_bwd")
+        return gx, None
 
 
 class TanhFn(torch.autograd.Function):
@@ -105,7 +106,8 @@ class ActCatFn(torch.autograd.Function):
         return (g[:, :z] if ctx.needs_input_grad[0] else None), gpre
 
 
-root_tanh = RootTanhFn.apply
+def root_tanh(x):
+    return RootTanhFn.apply(x, _slot_of(x) if x.is_contiguous() else None)
 tanh = TanhFn.apply
 act_cat = ActCatFn.apply
 
@@ -282,12 +284,73 @@ def reset_backward_state(*runtimes):
         rt.reset()
 
 
+# ------------------------------------------------------------------------------------------------
+# fan-out of one tensor into two consumers: the second backward kernel to arrive ADDS into the first one's buffer
+# ------------------------------------------------------------------------------------------------
+class _GradSlot:
+    """Gradient buffer shared by the backward kernels of the two consumers of a forked tensor.  claim() hands out the buffer
+    and says whether it already holds the other consumer's share (then the kernel accumulates)."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def claim(self, like, shape=None):
+        shape = tuple(like.shape if shape is None else shape)
+        if self.buf is None:
+            self.buf = like.new_empty(shape)
+            return self.buf, 0
+        return (self.buf if tuple(self.buf.shape) == shape else self.buf.view(shape)), 1
+
+
+class ForkFn(torch.autograd.Function):
+    """x -> (x, x) as two autograd branches.  Where one tensor feeds two of this package's kernels (a block's input: skip
+    branch and conv branch; an attention gate's input: the gate itself and the branch's norm), autograd would add the two
+    gradients with one more launch and one more pass over the tensor.  Consumers that know about the fork (inplace_norm,
+    residual_gate, feature_pool) write into ONE shared buffer instead - whichever backward kernel runs second accumulates
+    (`accumulate` flags of the C ABI) - and both return that buffer; then there is nothing left to add here.  A consumer that
+    does not take part simply returns its own gradient and the sum is formed as usual."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        slot, ctx.slot = ctx.slot, None
+        slot.buf = None
+        if ga is None or gb is None:
+            return (gb if ga is None else ga), None
+        if ga.data_ptr() == gb.data_ptr():
+            return ga, None
+        return ga + gb, None
+
+
+def fork(x):
+    """Two aliases of x for its two consumers (see ForkFn); a no-op when no gradient will flow."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    slot = _GradSlot()
+    a, b = ForkFn.apply(x, slot)
+    a._locate_slot = b._locate_slot = slot
+    stats = getattr(x, "_locate_stats", None)      # partial norm statistics left by x's producer (residual_gate)
+    if stats is not None:
+        a._locate_stats = b._locate_stats = stats
+    return a, b
+
+
+def _slot_of(x):
+    return getattr(x, "_locate_slot", None)
+
+
 class InPlaceNormFn(torch.autograd.Function):
     """out = (x - mean(x)) * scale / std(x) + bias with global scalar statistics.  With `with_act` the forward
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
-    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None):
+    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None, slot=None):
+        ctx.slot = slot
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
@@ -317,13 +380,13 @@ class InPlaceNormFn(torch.autograd.Function):
         x, scale, bias, stats = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
-        dx = torch.empty_like(x)
+        dx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
         dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device)
         dbias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
-                                _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), st), "locate_norm_bwd")
-        return dx, dscale, dbias, None, None, None
+                                _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), acc, st), "locate_norm_bwd")
+        return dx, dscale, dbias, None, None, None, None
 
 
 def inplace_norm(x, scale, bias, with_act=False, runtime=None):
@@ -331,7 +394,7 @@ def inplace_norm(x, scale, bias, with_act=False, runtime=None):
     # statistics partials left by the gate kernel that produced x (residual_gate): usable if taken for the same grouping
     pre = getattr(x, "_locate_stats", None)
     pre_partial = pre[0] if (pre is not None and pre[1] == groups and x.is_contiguous()) else None
-    return InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial)
+    return InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -341,7 +404,8 @@ class GateFn(torch.autograd.Function):
     """out = (gamma * a + 1) * x;  `a` has x's shape or is [B, C, 1, 1] (one value per plane)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, stats_groups=0, holder=None):
+    def forward(ctx, x, a, gamma, stats_groups=0, holder=None, slot=None):
+        ctx.slot = slot
         x = _c(x, "gate input")
         a = _c(a, "gate attention")
         gamma = _c(gamma, "gate gamma")
@@ -371,22 +435,23 @@ class GateFn(torch.autograd.Function):
         L = lib()
         planes = x.shape[0] * x.shape[1]
         hw = x.numel() // planes
-        dx = torch.empty_like(x)
+        dx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
         da = torch.empty_like(a)
         dgamma = torch.empty_like(gamma)
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
         check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), _p(dgamma), planes, hw, _p(ws),
-                                _stream()), "locate_gate_bwd")
-        return dx, da, dgamma, None, None
+                                acc, _stream()), "locate_gate_bwd")
+        return dx, da, dgamma, None, None, None
 
 
 def residual_gate(x, a, gamma, runtime=None, with_stats=True):
     """out = (gamma a + 1) x.  with_stats: the kernel also leaves the InPlaceNorm statistics partials of `out` (for the
     runtime's current stacked-call grouping) on the result, so that a norm consuming it skips its own statistics pass."""
+    slot = _slot_of(x) if x.is_contiguous() else None
     if not with_stats:
-        return GateFn.apply(x, a, gamma)
+        return GateFn.apply(x, a, gamma, 0, None, slot)
     holder = []
-    out = GateFn.apply(x, a, gamma, (runtime or DEFAULT_RUNTIME).stacked, holder)
+    out = GateFn.apply(x, a, gamma, (runtime or DEFAULT_RUNTIME).stacked, holder, slot)
     if holder:
         out._locate_stats = holder[0]
     return out
@@ -444,7 +509,8 @@ class Upsample2xFn(torch.autograd.Function):
 
 class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
+        ctx.slot = slot
         x = _c(x, "avgpool input")
         B, C, H, W = x.shape
         y = torch.empty(B, C, H // 2, W // 2, dtype=x.dtype, device=x.device)
@@ -456,16 +522,20 @@ class AvgPool2Fn(torch.autograd.Function):
     def backward(ctx, g):
         B, C, H, W = ctx.shape
         g = _c(g)
-        gx = torch.empty(B, C, H, W, dtype=g.dtype, device=g.device)
-        check(lib().locate_avgpool2_bwd(_p(g), _p(gx), B * C, H, W, _stream()), "locate_avgpool2_bwd")
-        return gx
+        if ctx.slot is not None:
+            gx, acc = ctx.slot.claim(g, (B, C, H, W))
+        else:
+            gx, acc = torch.empty(B, C, H, W, dtype=g.dtype, device=g.device), 0
+        check(lib().locate_avgpool2_bwd(_p(g), _p(gx), B * C, H, W, acc, _stream()), "locate_avgpool2_bwd")
+        return gx, None
 
 
 class FeaturePoolFn(torch.autograd.Function):
     """FeaturePooling: the raw-view mean over r adjacent flat elements (libs/scale.py:12-16)."""
 
     @staticmethod
-    def forward(ctx, x, out_features):
+    def forward(ctx, x, out_features, slot=None):
+        ctx.slot = slot
         x = _c(x, "feature pooling input")     # the reference's .view() requires contiguity too
         B, C = x.shape[0], x.shape[1]
         if C % out_features:
@@ -479,14 +549,23 @@ class FeaturePoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
-        gx = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device)
-        check(lib().locate_feature_pool_bwd(_p(g), _p(gx), g.numel(), ctx.r, _stream()), "locate_feature_pool_bwd")
-        return gx, None
+        if ctx.slot is not None:
+            gx, acc = ctx.slot.claim(g, ctx.in_shape)
+        else:
+            gx, acc = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device), 0
+        check(lib().locate_feature_pool_bwd(_p(g), _p(gx), g.numel(), ctx.r, acc, _stream()), "locate_feature_pool_bwd")
+        return gx, None, None
 
 
 upsample2x = Upsample2xFn.apply
-avgpool2 = AvgPool2Fn.apply
-feature_pool = FeaturePoolFn.apply
+
+
+def avgpool2(x):
+    return AvgPool2Fn.apply(x, _slot_of(x) if x.is_contiguous() else None)
+
+
+def feature_pool(x, out_features):
+    return FeaturePoolFn.apply(x, out_features, _slot_of(x) if x.is_contiguous() else None)
 
 
 def _copy_channels(src, dst, accumulate=False):

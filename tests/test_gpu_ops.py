@@ -290,6 +290,14 @@ CONV_CASES = [
     # maps so small that most taps only ever see padding (the contraction runs over the useful taps only)
     ("conv", 64, 64, 5, 2, 2, 6, 2, 2),       # 2x2 -> 1x1: 4 of 25 taps (the discriminator's last block)
     ("conv", 32, 48, 3, 1, 1, 5, 1, 1),       # 3x3 p1 on a 1x1 map: the centre tap only (the discriminator's head)
+    # 1x1 maps: the direct fp32 kernels (skinny_rows_kernel / skinny_wgrad_kernel)
+    ("conv", 256, 192, 1, 1, 0, 64, 1, 1),    # a style linear: 8 reduction chunks, one per wave
+    ("conv", 832, 384, 1, 1, 0, 64, 1, 1),    # 26 chunks: the prefetch loop; 6 column tiles
+    ("conv", 112, 48, 1, 1, 0, 64, 1, 1),     # ragged reduction (112 = 3.5 chunks), one partial column tile
+    ("conv", 12, 48, 1, 1, 0, 64, 1, 1),      # reduction shorter than a chunk
+    ("conv", 100, 7, 1, 1, 0, 5, 1, 1),       # ragged everything: 5 batch rows (tiles of 4), 7 outputs
+    ("convT", 64, 96, 1, 1, 0, 6, 1, 1),      # transposed layer on a 1x1 map (weights [C_in, C_out])
+    ("conv", 768, 12, 1, 1, 0, 192, 1, 1),    # batch 192
     ("conv", 16, 16, 5, 2, 2, 3, 3, 3),       # 3x3 -> 2x2: 4 of 5 rows / columns
     ("convT", 32, 32, 4, 2, 1, 3, 1, 1),      # transposed 1x1 -> 2x2: one tap per sub-pixel phase
     ("conv", 8, 8, 5, 2, 2, 2, 1, 5),         # 1 x 5 map: one useful row, all five columns
@@ -750,3 +758,44 @@ def test_split_k_combined_in_launch_is_reproducible_and_matches_the_reduction_ke
     monkeypatch.setattr(ops, "_counters", lambda owner, adjoint: None)      # NULL counters: the reduction-kernel path
     legacy = run()
     assert_close(first.cpu(), legacy.cpu(), 1e-6, "in-launch combine vs reduction kernel")
+
+
+
+@pytest.mark.parametrize("first,second", [("gate", "norm"), ("gate", "roottanh"), ("feature_pool", "norm"), ("avgpool", "norm"),
+                                          ("norm", "gate")])
+def test_forked_tensor_second_backward_kernel_accumulates(first, second):
+    """ops.fork: the backward kernels of a tensor's two consumers share one gradient buffer (the second to run adds into it,
+    `accumulate` of the C ABI) - against the same graph with autograd forming the sum."""
+    from locate_amd import ops
+    torch.manual_seed(11)
+    B, C, H, W = 6, 16, 12, 12
+    x0 = torch.randn(B, C, H, W, device=dev())
+    gamma0 = torch.full((1, 1), 1.7, device=dev())
+    scale0, bias0 = torch.randn(1, C, 1, 1, device=dev()), torch.randn(1, C, 1, 1, device=dev())
+    branch0 = torch.randn(B, C, H, W, device=dev())
+
+    def consume(kind, t, leaves):
+        if kind == "gate":
+            return ops.residual_gate(t, leaves["branch"], leaves["gamma"]).square().sum()
+        if kind == "norm":
+            return (ops.inplace_norm(t, leaves["scale"], leaves["bias"], False) * leaves["branch"]).sum()
+        if kind == "roottanh":
+            return (ops.root_tanh(t) * leaves["branch"]).sum()
+        if kind == "feature_pool":
+            return ops.feature_pool(t, C // 2).square().sum()
+        return ops.avgpool2(t).square().sum()
+
+    grads = []
+    for forked in (True, False):
+        leaves = {"gamma": gamma0.clone().requires_grad_(True), "scale": scale0.clone().requires_grad_(True),
+                  "bias": bias0.clone().requires_grad_(True), "branch": branch0.clone().requires_grad_(True)}
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                     # a non-leaf, as inside the networks
+        a, b = ops.fork(h) if forked else (h, h)
+        assert (getattr(a, "_locate_slot", None) is not None) == forked
+        (consume(first, a, leaves) + consume(second, b, leaves)).backward()
+        grads.append([x.grad] + [leaves[k].grad for k in ("gamma", "scale", "bias", "branch")])
+    for name, got, want in zip(("dx", "dgamma", "dscale", "dbias", "dbranch"), *grads):
+        if got is None and want is None:
+            continue
+        assert_close(got.cpu(), want.cpu(), 2e-6, name)

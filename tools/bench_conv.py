@@ -33,15 +33,76 @@ SHAPES = [
 
 
 def time_it(fn, reps):
+    """Milliseconds per call, the calls replayed from a captured hipGraph: small launches are otherwise paced by the host
+    (ctypes + planning: ~10 us per call), which the step's own graph replay does not pay either."""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(3):
+        graph.replay()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / (3 * reps)
+
+
+def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, use_cnt=True, dev=None):
+    """(ms forward, ms input gradient, ms weight gradient, algorithmic FLOPs, bytes forward) of one layer through the C ABI."""
+    dev = dev or torch.device("cuda:0")
+    L = lib()
+    S = lambda: torch.cuda.current_stream().cuda_stream          # evaluated per call: the graph capture runs on a side stream
+    spec = ops.ConvSpec(kind, kh, kw, s, ph, pw)
+    wshape = (cout, cin, kh, kw) if kind == "conv" else (cin, cout, kh, kw)
+    w = torch.randn(wshape, device=dev) * 0.05
+    x = torch.randn(B, cin, H, W, device=dev)
+    geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+    garr = (ctypes.c_int * 12)(*geom)
+    y = torch.empty(out_shape, device=dev)
+    gy = torch.randn(out_shape, device=dev)
+    gx = torch.empty_like(x)
+    gw = torch.empty_like(w)
+    one = torch.ones(1, device=dev)
+    pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0), 16), dtype=torch.uint8, device=dev)
+    pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1), 16), dtype=torch.uint8, device=dev)
+    check(L.locate_conv_pack_panel(garr, 0, w.data_ptr(), pan0.data_ptr(), S()))
+    check(L.locate_conv_pack_panel(garr, 1, w.data_ptr(), pan1.data_ptr(), S()))
+    ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+    ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+    part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
+    ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+    cnt_f = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
+    cnt_d = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
+
+    def r_fwd(inp, out):      # R forward
+        check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
+                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, S()))
+
+    def r_dgrad(inp, out):    # R data adjoint
+        check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
+                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, S()))
+
+    if kind == "conv":
+        fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
+        wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
+                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, S()))
+        flops = 2.0 * B * out_shape[2] * out_shape[3] * cout * cin * kh * kw
+    else:
+        fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
+        wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
+                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, S()))
+        flops = 2.0 * B * H * W * cout * cin * kh * kw        # every input pixel meets every tap once
+    ms = [time_it(f, reps) for f in (fwd, dgr, wgr)]
+    nbytes = 4.0 * (x.numel() + y.numel()) + 6.0 * w.numel()      # activations once each + the three bf16 weight planes
+    return ms, flops, nbytes
 
 
 def main():
@@ -50,62 +111,20 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on the stage name")
     ap.add_argument("--bf16", action="store_true", help="bf16 operands (precision 1) instead of the fp32-faithful splits")
     ap.add_argument("--no-counters", action="store_true", help="NULL arrival counters: split-K partial tiles summed by the reduction kernel")
+    ap.add_argument("--shape", action="append", default=[], help="extra stage: kind,Cin,Cout,k,stride,pad,H,B (replaces the list)")
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
-    L = lib()
-    st = torch.cuda.current_stream().cuda_stream
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
-    for name, kind, cin, cout, k, s, p, H, B in SHAPES:
+    shapes = SHAPES
+    if args.shape:
+        shapes = []
+        for t in args.shape:
+            f = t.split(",")
+            shapes.append((t, f[0]) + tuple(int(v) for v in f[1:]))
+    for name, kind, cin, cout, k, s, p, H, B in shapes:
         if args.only and args.only not in name:
             continue
-        spec = ops.ConvSpec(kind, k, k, s, p, p)
-        wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
-        w = torch.randn(wshape, device=dev) * 0.05
-        x = torch.randn(B, cin, H, H, device=dev)
-        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
-        garr = (ctypes.c_int * 12)(*geom)
-        y = torch.empty(out_shape, device=dev)
-        gy = torch.randn(out_shape, device=dev)
-        gx = torch.empty_like(x)
-        gw = torch.empty_like(w)
-        one = torch.ones(1, device=dev)
-        pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0), 16), dtype=torch.uint8, device=dev)
-        pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1), 16), dtype=torch.uint8, device=dev)
-        check(L.locate_conv_pack_panel(garr, 0, w.data_ptr(), pan0.data_ptr(), st))
-        check(L.locate_conv_pack_panel(garr, 1, w.data_ptr(), pan1.data_ptr(), st))
-        ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
-        ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
-        part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
-        ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
-
-        cnt_f = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
-        cnt_d = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
-        use_cnt = not args.no_counters
-        prec = 1 if args.bf16 else 0
-
-        def r_fwd(inp, out):      # R forward
-            check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                    out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, st))
-
-        def r_dgrad(inp, out):    # R data adjoint
-            check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                      out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, st))
-
-        if kind == "conv":
-            fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
-            wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, st))
-        else:
-            fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
-            wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
-                                                    w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, st))
-        OH = out_shape[2]
-        if kind == "conv":
-            flops = 2.0 * B * OH * OH * cout * cin * k * k
-        else:
-            flops = 2.0 * B * H * H * cout * cin * k * k        # every input pixel meets every tap once
-        ms = [time_it(f, args.reps) for f in (fwd, dgr, wgr)]
+        ms, flops, _ = bench_shape(kind, cin, cout, k, k, s, p, p, B, H, H, args.reps, 1 if args.bf16 else 0, not args.no_counters)
         for i in range(3):
             tot[i] += ms[i]
         print("%-28s %s" % (name, "  ".join("%6.3f|%6.1f" % (m, flops / m / 1e9) for m in ms)), flush=True)

@@ -51,7 +51,7 @@ def main():
         n = planes * hw
         x, g, y, gx = (torch.randn(shape, device=dev) for _ in range(4))
         report("RootTanh", shape, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, st)),
-               lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, st)), 2 * n, 3 * n)
+               lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, st)), 2 * n, 3 * n)
         w, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         dw, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
         stats = torch.empty(2, device=dev)
@@ -61,27 +61,27 @@ def main():
             report("InPlaceNorm" + (" + RootTanh" if act else ""), shape,
                    lambda act=act: check(L.locate_norm_fwd(P(x), P(w), 0, P(b), P(y), act, P(stats), Bn, C, hw, 1, P(ws_f), None, st)),
                    lambda act=act: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w), 0, P(b), act, P(gx), P(dw), P(db), Bn, C, hw, 1,
-                                                           P(ws_b), st)), 3 * n, 5 * n)    # statistics pass + apply | plane sums + dx
+                                                           P(ws_b), 0, st)), 3 * n, 5 * n)    # statistics pass + apply | plane sums + dx
         a = torch.randn(shape, device=dev)
         ac = torch.randn(Bn, C, device=dev)
         da, dac = torch.empty_like(a), torch.empty_like(ac)
         gam, dgam = torch.full((1,), 2.0, device=dev), torch.empty(1, device=dev)
         ws_g = torch.empty(max(L.locate_gate_bwd_workspace_bytes(planes), 16), dtype=torch.uint8, device=dev)
         report("gate, full attention map", shape, lambda: check(L.locate_gate_fwd(P(x), P(a), 0, P(gam), P(y), planes, hw, st)),
-               lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), st)), 3 * n, 5 * n)
+               lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, st)), 3 * n, 5 * n)
         report("gate, per-plane attention", shape, lambda: check(L.locate_gate_fwd(P(x), P(ac), 1, P(gam), P(y), planes, hw, st)),
-               lambda: check(L.locate_gate_bwd(P(x), P(ac), 1, P(gam), P(g), P(gx), P(dac), P(dgam), planes, hw, P(ws_g), st)), 2 * n, 3 * n)
+               lambda: check(L.locate_gate_bwd(P(x), P(ac), 1, P(gam), P(g), P(gx), P(dac), P(dgam), planes, hw, P(ws_g), 0, st)), 2 * n, 3 * n)
         report("softmax over H*W", shape, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)),
                lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)), 2 * n, 3 * n)
         if H == 64:
             q = torch.empty(Bn, C, H // 2, W // 2, device=dev)
             gq = torch.randn_like(q)
             report("avgpool 2x2", shape, lambda: check(L.locate_avgpool2_fwd(P(x), P(q), planes, H, W, st)),
-                   lambda: check(L.locate_avgpool2_bwd(P(gq), P(gx), planes, H, W, st)), n + n // 4, n + n // 4)
+                   lambda: check(L.locate_avgpool2_bwd(P(gq), P(gx), planes, H, W, 0, st)), n + n // 4, n + n // 4)
             h2 = torch.empty(Bn, C // 2, H, W, device=dev)
             gh2 = torch.randn_like(h2)
             report("FeaturePooling / 2", shape, lambda: check(L.locate_feature_pool_fwd(P(x), P(h2), n // 2, 2, st)),
-                   lambda: check(L.locate_feature_pool_bwd(P(gh2), P(gx), n // 2, 2, st)), n + n // 2, n + n // 2)
+                   lambda: check(L.locate_feature_pool_bwd(P(gh2), P(gx), n // 2, 2, 0, st)), n + n // 2, n + n // 2)
         else:
             up = torch.empty(Bn, C, 2 * H, 2 * W, device=dev)
             gup = torch.randn_like(up)
