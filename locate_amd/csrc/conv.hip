@@ -915,20 +915,26 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        constexpr int HB = 4;
-        for (int z = 0; z < p.ksplit; ++z) {
-            const unsigned zb = t0 + (unsigned)z * zstride;
+        // four fragments of four consecutive z in flight (16 loads: this block is the launch's tail, every round trip it
+        // waits for is exposed); a z beyond ksplit lies beyond the descriptor's extent and reads as 0
+        constexpr int HB = 4, ZB = 4;
 #pragma unroll
-            for (int h0 = 0; h0 < FR; h0 += HB) {
-                u32x4 v[HB];
+        for (int h0 = 0; h0 < FR; h0 += HB) {
+            for (int z0 = 0; z0 < p.ksplit; z0 += ZB) {
+                u32x4 v[ZB][HB];
 #pragma unroll
-                for (int f = 0; f < HB; ++f) v[f] = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(zb + (unsigned)((h0 + f) * 256 * 16)), 0, 16);
+                for (int zz = 0; zz < ZB; ++zz)
 #pragma unroll
-                for (int f = 0; f < HB; ++f) {
-                    const int g = h0 + f, i = g / (TN * 4), j = (g / 4) % TN, q = g % 4;
+                    for (int f = 0; f < HB; ++f)
+                        v[zz][f] = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(t0 + (unsigned)(z0 + zz) * zstride + (unsigned)((h0 + f) * 256 * 16)), 0, 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += __uint_as_float(v[f][e]);
-                }
+                for (int zz = 0; zz < ZB; ++zz)
+#pragma unroll
+                    for (int f = 0; f < HB; ++f) {
+                        const int g = h0 + f, i = g / (TN * 4), j = (g / 4) % TN, q = g % 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += __uint_as_float(v[zz][f][e]);
+                    }
             }
         }
         __syncthreads();      // the flag word's patch neighbours are about to be reused by the staged epilogue
@@ -950,8 +956,24 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         unsigned b, r;
         dpb.divmod(i, b, r);
+        // eight slabs' loads in flight, added in z order (one load - wait - add per slab is ksplit exposed round trips)
         float acc = 0.0f;
-        for (int z = 0; z < ksplit; ++z) acc += slab[(long long)z * slab_stride + i];
+        const float* __restrict__ sp = slab + i;
+        int z = 0;
+        for (; z + 8 <= ksplit; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = sp[(long long)(z + q) * slab_stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = z + q < ksplit ? sp[(long long)(z + q) * slab_stride] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];          // + 0.0f beyond ksplit: exact
+        }
         if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
         if (bias) acc += bias[dpl.div(r)];
         out[(long long)b * out_bs + r] = acc;
@@ -1985,8 +2007,17 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
     for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < n; i0 += stride) {
         const int64_t i = i0 + ex;
         float acc = 0.0f;
-        if (i < n)
-            for (int z = ez; z < nsplit; z += ZP) acc += slab[(int64_t)z * n + i];
+        if (i < n) {
+            // eight slabs' loads in flight, added in z order
+            const float* __restrict__ sp = slab + i;
+            for (int z = ez; z < nsplit; z += 8 * ZP) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < nsplit ? sp[(int64_t)(z + q * ZP) * n] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];      // + 0.0f beyond nsplit: exact
+            }
+        }
         if (ZP > 1) {
             __syncthreads();
             zsum[ez][ex] = acc;
