@@ -114,17 +114,32 @@ __global__ void __launch_bounds__(256) sn_rowdot_kernel(const SnLayer single, co
 }
 
 // one block per layer: normalise and publish u, v, sigma, wv
+// (1024 threads and four independent loads per pass: one block walks up to 19 200 columns three times, and at 256 threads with
+// one load in flight each pass was a chain of 75 exposed round trips - 33 us for the widest layer, now 8)
 template <bool BATCHED>
-__global__ void __launch_bounds__(256) sn_finalize_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
+__global__ void __launch_bounds__(1024) sn_finalize_kernel(const SnLayer single, const SnLayer* __restrict__ table) {
     __shared__ double scratch[16];
     const SnLayer L = sn_get<BATCHED>(single, table);
     const float eps = 1e-12f;
+    const float* __restrict__ tp = L.t;
     double a = 0.0;
-    for (int j = threadIdx.x; j < L.wd; j += blockDim.x) a += (double)L.t[j] * (double)L.t[j];
+    {
+        int j = threadIdx.x;
+        for (; j + 3 * (int)blockDim.x < L.wd; j += 4 * blockDim.x) {
+            const float t0 = tp[j], t1 = tp[j + blockDim.x], t2 = tp[j + 2 * blockDim.x], t3 = tp[j + 3 * blockDim.x];
+            a += (double)t0 * (double)t0;
+            a += (double)t1 * (double)t1;
+            a += (double)t2 * (double)t2;
+            a += (double)t3 * (double)t3;
+        }
+        for (; j < L.wd; j += blockDim.x) a += (double)tp[j] * (double)tp[j];
+    }
     a = block_sum<double>(a, scratch);
     const float nt = (float)sqrt(a);
     const float dt = nt + eps;
-    for (int j = threadIdx.x; j < L.wd; j += blockDim.x) L.v[j] = L.t[j] / dt;
+    float* __restrict__ vp = L.v;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < L.wd; j += blockDim.x) vp[j] = tp[j] / dt;
     double b = 0.0;
     for (int i = threadIdx.x; i < L.h; i += blockDim.x) {
         const float si = L.s[i] / dt;     // (W v)[i]
@@ -176,7 +191,7 @@ LOCATE_API int locate_sn_power_iter(const float* w, float* u, float* v, float* s
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(tsum)");
     sn_rowdot_kernel<false><<<wd >= SN_WIDE ? h : (h + 3) / 4, 256, 0, st>>>(L, nullptr);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(rowdot)");
-    sn_finalize_kernel<false><<<1, 256, 0, st>>>(L, nullptr);
+    sn_finalize_kernel<false><<<1, 1024, 0, st>>>(L, nullptr);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter(finalize)");
     return LOCATE_OK;
 }
@@ -198,7 +213,7 @@ LOCATE_API int locate_sn_power_iter_batched(const void* table, int n_layers, int
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(tsum)");
     sn_rowdot_kernel<true><<<dim3(max_wd >= SN_WIDE ? max_h : (max_h + 3) / 4, n_layers), 256, 0, st>>>(dummy, tab);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(rowdot)");
-    sn_finalize_kernel<true><<<dim3(1, n_layers), 256, 0, st>>>(dummy, tab);
+    sn_finalize_kernel<true><<<dim3(1, n_layers), 1024, 0, st>>>(dummy, tab);
     LOCATE_LAUNCH_CHECK("locate_sn_power_iter_batched(finalize)");
     return LOCATE_OK;
 }
