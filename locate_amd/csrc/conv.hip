@@ -2074,6 +2074,219 @@ static int wgrad_reduce_grid(int64_t n, int nsplit) {
     return g > 2048 ? 2048 : g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of 1x1 stride-1 layers with few channels on both sides (<= 128: the attention gates' convs, the skip
+// branches' 1x1 convs, the generator's head) over many pixels:  gw[m][c] = sum_{b, p} gy[b][m][p] x[b][c][p].
+// Both operands are contiguous along the reduction index p, which is exactly the MFMA fragment layout (lane (r, h) holds
+// k = 8h .. 8h + 7 of row r): every wave loads its fragments straight from global memory - two 16-byte loads per fragment
+// row - splits them in registers and multiplies; no LDS image, no barrier, no gather tables in the loop.  These launches
+// are HBM streams (a 64 x 64 output tile per wave against 8 KB of operands per 16 pixels); the general kernel above, built
+// for wide layers, ran them at 15-25 % of that.  A wave owns one (row tile, column tile) and a contiguous run of 16-pixel
+// steps; the four waves of a block add their tiles in wave order through LDS and write one slab, summed (with 1/sigma and
+// the <G, W_bar> partials) by slab_reduce_kernel like every split weight gradient.
+// ---------------------------------------------------------------------------------------------
+struct PwParams {
+    const float* x;
+    const float* gy;
+    float* slab;
+    const float* inv_scale;
+    long long x_bs, gy_bs;
+    int B, C, M, P;            // P = H * W
+    int N;                     // B * P
+    int steps, chunk;          // 16-pixel steps in all, steps per wave
+    int tiles_c;
+    int gscale_bg, gscale_stride;
+};
+
+template <int TM, int TN, int NP>
+__global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
+    __shared__ float red[3][TM * TN * 16][64];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int tm = blockIdx.y / p.tiles_c, tc = blockIdx.y - tm * p.tiles_c;
+    const int m0 = tm * (TM * 32), c0 = tc * (TN * 32);
+    const int z = blockIdx.x * 4 + wid;
+    const int s_begin = z * p.chunk;
+    int s_end = s_begin + p.chunk;
+    if (s_end > p.steps) s_end = p.steps;
+
+    float gs0 = 1.0f, gs1 = 1.0f, gs2 = 1.0f, gs3 = 1.0f;
+    if (p.gscale_bg > 0) {
+        const int ng = p.B / p.gscale_bg;
+        gs0 = p.inv_scale[0];
+        gs1 = ng > 1 ? p.inv_scale[p.gscale_stride] : 1.0f;
+        gs2 = ng > 2 ? p.inv_scale[2 * p.gscale_stride] : 1.0f;
+        gs3 = ng > 3 ? p.inv_scale[3 * p.gscale_stride] : 1.0f;
+    }
+    // rows of this lane's fragments (clamped to a valid row; masked when beyond the tensor)
+    long long arow[TM], brow[TN];
+    bool aok[TM], bok[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 32 + lcol;
+        aok[i] = m < p.M;
+        arow[i] = (long long)(aok[i] ? m : 0) * p.P;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + j * 32 + lcol;
+        bok[j] = c < p.C;
+        brow[j] = (long long)(bok[j] ? c : 0) * p.P;
+    }
+    const DivU32 dp((unsigned)p.P);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ca[TM][2], cb[TN][2], na[TM][2], nb[TN][2];
+    float csc = 1.0f, nsc = 1.0f;
+    auto load = [&](int s, float4 (&fa)[TM][2], float4 (&fb)[TN][2], float& sc) {
+        // this lane's eight pixels n .. n + 7 of step s (P % 8 == 0: they lie in one image)
+        const unsigned n = (unsigned)s * 16u + 8u * (unsigned)lrow;
+        const bool ok = s < s_end && n < (unsigned)p.N;
+        unsigned b, q;
+        dp.divmod(ok ? n : 0u, b, q);
+        const float* gp = p.gy + (long long)b * p.gy_bs + q;
+        const float* xp = p.x + (long long)b * p.x_bs + q;
+        sc = 1.0f;
+        if (p.gscale_bg > 0) {
+            const int bg = p.gscale_bg;
+            sc = gs0;
+            sc = (int)b >= bg ? gs1 : sc;
+            sc = (int)b >= 2 * bg ? gs2 : sc;
+            sc = (int)b >= 3 * bg ? gs3 : sc;
+        }
+        if (!ok) sc = 0.0f;                                  // beyond this wave's run: the loads below are valid, the values dropped
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float4* g4 = reinterpret_cast<const float4*>(gp + arow[i]);
+            fa[i][0] = g4[0];
+            fa[i][1] = g4[1];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4* x4 = reinterpret_cast<const float4*>(xp + brow[j]);
+            fb[j][0] = x4[0];
+            fb[j][1] = x4[1];
+        }
+    };
+    if (s_begin < s_end) load(s_begin, ca, cb, csc);
+    for (int s = s_begin; s < s_end; ++s) {
+        load(s + 1, na, nb, nsc);
+        bf16x8 a[TM][NP], b[TN][NP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float w = aok[i] ? csc : 0.0f;
+            float v[8] = {ca[i][0].x * w, ca[i][0].y * w, ca[i][0].z * w, ca[i][0].w * w,
+                          ca[i][1].x * w, ca[i][1].y * w, ca[i][1].z * w, ca[i][1].w * w};
+            if constexpr (NP == 3) {
+                uint4 h, m, l;
+                split3_trunc_x8(v, h, m, l);
+                a[i][0] = *reinterpret_cast<bf16x8*>(&h);
+                a[i][NP - 2] = *reinterpret_cast<bf16x8*>(&m);
+                a[i][NP - 1] = *reinterpret_cast<bf16x8*>(&l);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[i][0][e] = (__bf16)v[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float w = (bok[j] && csc != 0.0f) ? 1.0f : 0.0f;
+            float v[8] = {cb[j][0].x * w, cb[j][0].y * w, cb[j][0].z * w, cb[j][0].w * w,
+                          cb[j][1].x * w, cb[j][1].y * w, cb[j][1].z * w, cb[j][1].w * w};
+            if constexpr (NP == 3) {
+                uint4 h, m, l;
+                split3_trunc_x8(v, h, m, l);
+                b[j][0] = *reinterpret_cast<bf16x8*>(&h);
+                b[j][NP - 2] = *reinterpret_cast<bf16x8*>(&m);
+                b[j][NP - 1] = *reinterpret_cast<bf16x8*>(&l);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[j][0][e] = (__bf16)v[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (NP == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);        // l h
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);        // h l
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][0], acc[i][j], 0, 0, 0);        // m h
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 2], acc[i][j], 0, 0, 0);        // h m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);             // h h
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ca[i][0] = na[i][0]; ca[i][1] = na[i][1]; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { cb[j][0] = nb[j][0]; cb[j][1] = nb[j][1]; }
+        csc = nsc;
+    }
+    // the block's four tiles, added in wave order; wave 0 writes the slab
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wid - 1][(i * TN + j) * 16 + r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wid != 0) return;
+    float* out = p.slab + (long long)blockIdx.x * p.M * p.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + j * 32 + lcol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const int e = (i * TN + j) * 16 + r;
+                const float v = ((acc[i][j][r] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
+                if (m < p.M && c < p.C) out[(long long)m * p.C + c] = v;
+            }
+        }
+}
+
+struct PwPlan {
+    bool ok;
+    int tm, tn, tiles_m, tiles_c, steps, chunk, nslab;
+};
+
+static PwPlan pw_plan(const ConvGeom& g) {
+    PwPlan q;
+    const long long P = (long long)g.H * g.W;
+    q.ok = !path_disabled("pwgrad") && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H &&
+           g.OW == g.W && (P % 8) == 0 && g.M <= 128 && g.C <= 128 && (long long)g.B * P >= 4096 && (long long)g.B * P < (1ll << 31);
+    q.tm = g.M <= 32 ? 1 : 2;
+    q.tn = g.C <= 32 ? 1 : 2;
+    q.tiles_m = (g.M + q.tm * 32 - 1) / (q.tm * 32);
+    q.tiles_c = (g.C + q.tn * 32 - 1) / (q.tn * 32);
+    const long long N = (long long)g.B * P;
+    q.steps = (int)((N + 15) / 16);
+    // ~2048 waves (two per SIMD) over all tiles, at least 8 steps each
+    const int tiles = q.tiles_m * q.tiles_c;
+    int waves = 2048 / tiles;
+    if (waves < 4) waves = 4;
+    int chunk = (q.steps + waves - 1) / waves;
+    if (chunk < 8) chunk = 8;
+    q.chunk = chunk;
+    const int nw = (q.steps + chunk - 1) / chunk;
+    q.nslab = (nw + 3) / 4;
+    return q;
+}
+
 // Weight gradient of the same 1x1-map layers (skinny_rows_kernel): gw[m][c] = inv_scale * sum_n gy[n][m] x[n][c], an outer-product
 // sum over the 64 ... 192 batch rows.  lane = c (x[n][.] is one coalesced load), a block owns eight rows m (gy[n][m .. m + 7] is
 // wave-uniform: one scalar load) and its four waves a quarter of the batch each, plain fp32 FMAs, no slab; one partial of
@@ -2146,6 +2359,10 @@ static dim3 skinny_wgrad_grid(const ConvGeom& g) { return dim3((g.C + 63) / 64, 
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
     const ConvGeom g = make_geom(geom);
     if (skinny_wgrad_ok(g)) return 0;
+    {
+        const PwPlan q = pw_plan(g);
+        if (q.ok) return (size_t)q.nslab * g.M * g.C * sizeof(float);
+    }
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
     return nsplit > 1 ? (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float) : 0;
@@ -2157,6 +2374,10 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
     if (skinny_wgrad_ok(g)) {
         const dim3 grid = skinny_wgrad_grid(g);
         return (int)(grid.x * grid.y);
+    }
+    {
+        const PwPlan q = pw_plan(g);
+        if (q.ok) return wgrad_reduce_grid((int64_t)g.M * g.C, q.nslab);
     }
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
@@ -2183,6 +2404,38 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         skinny_wgrad_kernel<<<skinny_wgrad_grid(g), 256, 0, st>>>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_group_batch, scale_stride,
                                                                   inner_partial, g.B, g.M, g.C);
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(1x1 map)");
+        return LOCATE_OK;
+    }
+    const PwPlan pq = pw_plan(g);
+    if (pq.ok && (x_bs & 3) == 0 && (gy_bs & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
+        LOCATE_REQUIRE(workspace, "locate_conv_wgrad: the split reduction needs a workspace");
+        PwParams q;
+        q.x = x; q.gy = gy; q.slab = static_cast<float*>(workspace); q.x_bs = x_bs; q.gy_bs = gy_bs;
+        q.B = g.B; q.C = g.C; q.M = g.M; q.P = g.H * g.W; q.N = g.B * g.H * g.W; q.steps = pq.steps; q.chunk = pq.chunk;
+        q.tiles_c = pq.tiles_c;
+        const bool grouped = scale_group_batch > 0;
+        q.inv_scale = grouped ? inv_scale : nullptr; q.gscale_bg = scale_group_batch; q.gscale_stride = scale_stride;
+        const dim3 grid(pq.nslab, pq.tiles_m * pq.tiles_c);
+        const int key = (pq.tm - 1) * 2 + (pq.tn - 1);
+        if (precision == 1) {
+            if (key == 0) pw_wgrad_kernel<1, 1, 1><<<grid, 256, 0, st>>>(q);
+            else if (key == 1) pw_wgrad_kernel<1, 2, 1><<<grid, 256, 0, st>>>(q);
+            else if (key == 2) pw_wgrad_kernel<2, 1, 1><<<grid, 256, 0, st>>>(q);
+            else pw_wgrad_kernel<2, 2, 1><<<grid, 256, 0, st>>>(q);
+        } else {
+            if (key == 0) pw_wgrad_kernel<1, 1, 3><<<grid, 256, 0, st>>>(q);
+            else if (key == 1) pw_wgrad_kernel<1, 2, 3><<<grid, 256, 0, st>>>(q);
+            else if (key == 2) pw_wgrad_kernel<2, 1, 3><<<grid, 256, 0, st>>>(q);
+            else pw_wgrad_kernel<2, 2, 3><<<grid, 256, 0, st>>>(q);
+        }
+        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(pointwise)");
+        const int64_t n = (int64_t)g.M * g.C;
+        const int rg = wgrad_reduce_grid(n, pq.nslab);
+        const int zp = wgrad_reduce_zp(pq.nslab, n);
+        if (zp == 16) slab_reduce_kernel<16><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
+        else if (zp == 4) slab_reduce_kernel<4><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
+        else slab_reduce_kernel<1><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
+        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(pointwise reduce)");
         return LOCATE_OK;
     }
     int bm, nsplit, chunk, tiles;

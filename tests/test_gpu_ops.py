@@ -290,6 +290,11 @@ CONV_CASES = [
     # maps so small that most taps only ever see padding (the contraction runs over the useful taps only)
     ("conv", 64, 64, 5, 2, 2, 6, 2, 2),       # 2x2 -> 1x1: 4 of 25 taps (the discriminator's last block)
     ("conv", 32, 48, 3, 1, 1, 5, 1, 1),       # 3x3 p1 on a 1x1 map: the centre tap only (the discriminator's head)
+    # 1x1 layers with <= 128 channels over many pixels: the weight gradient straight from global-memory fragments (pw_wgrad_kernel)
+    ("conv", 96, 48, 1, 1, 0, 16, 32, 32),    # two column tiles
+    ("conv", 40, 100, 1, 1, 0, 8, 32, 32),    # two row tiles, ragged both ways
+    ("conv", 24, 32, 1, 1, 0, 64, 6, 12),     # H * W = 72: a multiple of 8 but not of 16 (a step straddles two images)
+    ("conv", 3, 29, 1, 1, 0, 12, 64, 64),     # the discriminator's first skip conv: 32 x 32 tiles, mostly masked
     # 1x1 maps: the direct fp32 kernels (skinny_rows_kernel / skinny_wgrad_kernel)
     ("conv", 256, 192, 1, 1, 0, 64, 1, 1),    # a style linear: 8 reduction chunks, one per wave
     ("conv", 832, 384, 1, 1, 0, 64, 1, 1),    # 26 chunks: the prefetch loop; 6 column tiles
