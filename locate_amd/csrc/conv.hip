@@ -666,15 +666,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // NP = 3: the exact three-piece form above.  NP = 1: "bf16 operands" - both operands rounded (to nearest even) to ONE bf16
 // piece, one MFMA per slice, fp32 accumulation: the precision of a bf16 mixed-precision training step (BASELINE configs[1]),
 // a third of the LDS traffic and a sixth of the matrix work.  Storage stays fp32 on both sides of the kernel.
-template <int WGM, int WGN, int TM, int TN, int NP>
-__global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_kernel(const IgParams p) {
-    constexpr int BK = B6_BK, KB = BK / 8;
+// NW = 8: eight waves on the same 128-column tile with K steps of 32 - every thread still gathers ONE fragment per stage, so a
+// stage covers twice the reduction depth at the same per-thread work, each wave owns half the rows of a four-wave tile, and two
+// waves per SIMD cover each other's waits: for launches that cannot put more than one block on a CU anyway (mid-sized layers:
+// a hundred-odd tiles), where a lone four-wave block walks its K loop at ~1.2 us per 16-deep stage.
+template <int WGM, int WGN, int TM, int TN, int NP, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3))) conv_igemm_bx6_kernel(const IgParams p) {
+    constexpr int BK = 4 * NW, KB = BK / 8, KS = BK / 16, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
-    static_assert(WGM * WGN == 4, "four waves");
-    static_assert(BN == 128 && KB * BN == 256, "one gathered fragment (k-block) per thread and stage");
-    static_assert(KB * BM <= 512, "at most two weight fragments per thread and stage");
-    constexpr bool A2 = KB * BM > 256;      // tall tiles (BM = 192: 64 x 96 per wave, twice the MFMAs per gathered element)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(WGM * WGN == NW, "wave grid");
+    static_assert(BN == 128 && KB * BN == NT, "one gathered fragment (k-block) per thread and stage");
+    static_assert(KB * BM <= 2 * NT, "at most two weight fragments per thread and stage");
+    static_assert(B6_BK == 16, "the host's split-K accounting counts 16-deep steps");
+    constexpr bool A2 = KB * BM > NT;       // tall tiles (BM = 192: 64 x 96 per wave, twice the MFMAs per gathered element)
     // the pipeline issues the loads of two stages beyond the last one (tiles nsteps and nsteps + 1): their weight chunks and
     // offset-table rows must lie inside the panel's zero tail
     static_assert(2 * BK <= IG_TAIL && (IG_TAIL % 8) == 0, "panel tail shorter than the prefetch distance");
@@ -683,7 +689,7 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
     // operand images of the K loop, then - they are dead after its last barrier - four 32 x 33 float patches of the staged
     // epilogue and the split-K "I am last" word
     constexpr int A_U4 = 2 * NP * KB * BM, B_U4 = 2 * NP * KB * BN;
-    constexpr int EPI_U4 = (4 * 32 * 33 + 8 + 3) / 4;
+    constexpr int EPI_U4 = (NW * 32 * 33 + 8 + 3) / 4;
     constexpr int SMEM_U4 = A_U4 + B_U4 > EPI_U4 ? A_U4 + B_U4 : EPI_U4;
     __shared__ uint4 smem[SMEM_U4];
     uint4 (*As)[NP][KB][BM] = reinterpret_cast<uint4 (*)[NP][KB][BM]>(smem);
@@ -725,15 +731,15 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
     if (nsteps < 0) nsteps = 0;
 
     // weight fragment of this thread: chunk (k-block a_kb, column m0 + a_m) of the three pre-split planes
-    const bool a_thread = KB * BM == 256 || tid < KB * BM;
+    const bool a_thread = KB * BM == NT || tid < KB * BM;
     const int a_kb = a_thread ? tid / BM : 0, a_m = a_thread ? tid % BM : 0;
     // every tile column lies inside the panel: ld = round_up(M, 32) = round_up(M, BM) for the BM pick_bm() chooses (checked by
     // launch_igemm), and the columns M .. ld - 1 are zero - no masking in the loop
     const uint4* ap = ph.w3 + (long long)(step0 * KB + a_kb) * ph.ld + (m0 + a_m);
     const long long a_step = (long long)KB * ph.ld, a_plane = ph.w3_plane;
-    // second weight fragment of tall tiles: chunk index tid + 256
-    const bool b_thread = A2 && tid + 256 < KB * BM;
-    const int b_kb = b_thread ? (tid + 256) / BM : 0, b_m = b_thread ? (tid + 256) % BM : 0;
+    // second weight fragment of tall tiles: chunk index tid + NT
+    const bool b_thread = A2 && tid + NT < KB * BM;
+    const int b_kb = b_thread ? (tid + NT) / BM : 0, b_m = b_thread ? (tid + NT) % BM : 0;
     const uint4* bp = ph.w3 + (long long)(step0 * KB + b_kb) * ph.ld + (m0 + b_m);
     int kidx = step0 * BK + kgrp * 8;                             // wave-uniform first table row of the next load
 
@@ -812,18 +818,21 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
     constexpr int PROD = NP == 3 ? 6 : 1;
-    constexpr int NMF = TM * TN * PROD, HALF = NMF / 2;
+    constexpr int NMF = TM * TN * PROD, HALF = KS == 1 ? NMF / 2 : NMF;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         bf16x8 a[TM][NP], b[TN][NP];
+        auto fragments = [&](int ksub) {          // the 16-deep slice `ksub` of the stage
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][lrow][(wm * TM + i) * 32 + lcol]);
+                for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][2 * ksub + lrow][(wm * TM + i) * 32 + lcol]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][lrow][(wn * TN + j) * 32 + lcol]);
+                for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][2 * ksub + lrow][(wn * TN + j) * 32 + lcol]);
+        };
+        fragments(0);
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -848,12 +857,17 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
         store_tiles(buf ^ 1);                // tile s + 1
         __builtin_amdgcn_sched_barrier(0);
         issue_loads();                       // tile s + 2
-        mfmas(HALF, NMF);
+        if constexpr (KS == 1) {
+            mfmas(HALF, NMF);
+        } else {
+            fragments(1);                    // the stage's second 16-deep slice
+            mfmas(0, NMF);
+        }
         // one vector-memory instruction (and its address arithmetic) in the shadow of every MFMA: the memory pipe takes
         // ~100 cycles per wave instruction when twelve waves queue on it, the matrix pipe 32 per MFMA
         if constexpr (NP == 3) {
 #pragma unroll
-            for (int k = 0; k < NMF - HALF; ++k) {
+            for (int k = 0; k < (KS == 1 ? NMF - HALF : NMF); ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
@@ -877,7 +891,7 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
         constexpr int FR = TM * TN * 4;                                   // 16-byte fragments per thread
         const int tile = (zphase * (int)gridDim.y + by) * (int)gridDim.x + bx;
         const int ntiles = p.nphase * (int)gridDim.y * (int)gridDim.x;
-        const unsigned tile_bytes = FR * 256 * 16;
+        const unsigned tile_bytes = FR * NT * 16;
         __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)((unsigned)p.ksplit * ntiles * tile_bytes), 0x00020000);
         const unsigned my = ((unsigned)(zsplit * ntiles + tile)) * tile_bytes + (unsigned)tid * 16u;
 #pragma unroll
@@ -889,11 +903,11 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
                     u32x4 v;
                     v[0] = __float_as_uint(acc[i][j][4 * q + 0]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
                     v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, (int)(my + (unsigned)(((i * TN + j) * 4 + q) * 256 * 16)), 0, 16);   // aux 16 = sc1
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, (int)(my + (unsigned)(((i * TN + j) * 4 + q) * NT * 16)), 0, 16);   // aux 16 = sc1
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        unsigned* const flag = reinterpret_cast<unsigned*>(smem) + 4 * 32 * 33 + 4;     // beyond the four 32 x 33 patches
+        unsigned* const flag = reinterpret_cast<unsigned*>(smem) + NW * 32 * 33 + 4;    // beyond the waves' 32 x 33 patches
         if (tid == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = ticket == (unsigned)(p.ksplit - 1);
@@ -926,7 +940,7 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_bx6_ke
                 for (int zz = 0; zz < ZB; ++zz)
 #pragma unroll
                     for (int f = 0; f < HB; ++f)
-                        v[zz][f] = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(t0 + (unsigned)(z0 + zz) * zstride + (unsigned)((h0 + f) * 256 * 16)), 0, 16);
+                        v[zz][f] = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(t0 + (unsigned)(z0 + zz) * zstride + (unsigned)((h0 + f) * NT * 16)), 0, 16);
 #pragma unroll
                 for (int zz = 0; zz < ZB; ++zz)
 #pragma unroll
@@ -1270,7 +1284,18 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     dim3 grid(sp.gx, sp.gy, p.nphase * p.ksplit);
     for (int i = 0; i < p.nphase; ++i)
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
-    if (p.precision == 1) {
+    // launches of at most ~one block per CU: the eight-wave form (see the kernel)
+    const bool w8 = !path_disabled("w8") && !path_disabled("bx6") && (bm == 128 || bm == 64) &&
+                    (long long)grid.x * grid.y * grid.z <= 320;
+    if (w8) {
+        if (p.precision == 1) {
+            if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 1, 8><<<grid, 512, 0, st>>>(p);
+            else conv_igemm_bx6_kernel<2, 4, 1, 1, 1, 8><<<grid, 512, 0, st>>>(p);
+        } else {
+            if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 3, 8><<<grid, 512, 0, st>>>(p);
+            else conv_igemm_bx6_kernel<2, 4, 1, 1, 3, 8><<<grid, 512, 0, st>>>(p);
+        }
+    } else if (p.precision == 1) {
         if (bm == 192) conv_igemm_bx6_kernel<2, 2, 3, 2, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
