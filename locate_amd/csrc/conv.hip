@@ -1063,8 +1063,13 @@ static bool path_disabled(const char* name) {
     static const char* env = getenv("LOCATE_DISABLE");
     return env != nullptr && strstr(env, name) != nullptr;
 }
+static int knob_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return v != nullptr ? atoi(v) : fallback;
+}
 #else
 static constexpr bool path_disabled(const char*) { return false; }
+static constexpr int knob_int(const char*, int fallback) { return fallback; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -1226,6 +1231,7 @@ static int igemm_ksplit(int M, int nmax, int nphase, int min_kpad) {
     const int max_split = steps / min_steps > 0 ? steps / min_steps : 1;
     if (want > max_split) want = max_split;
     if (want > 64) want = 64;
+    if (want > knob_int("LOCATE_KS_MAX", 64)) want = knob_int("LOCATE_KS_MAX", 64);
     return want < 1 ? 1 : (int)want;
 }
 
@@ -1286,7 +1292,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
     // launches of at most ~one block per CU: the eight-wave form (see the kernel)
     const bool w8 = !path_disabled("w8") && !path_disabled("bx6") && (bm == 128 || bm == 64) &&
-                    (long long)grid.x * grid.y * grid.z <= 320;
+                    (long long)grid.x * grid.y * grid.z <= knob_int("LOCATE_W8_MAX", 320);
     if (w8) {
         if (p.precision == 1) {
             if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 1, 8><<<grid, 512, 0, st>>>(p);
