@@ -52,9 +52,11 @@ class TrainStep:
         self.d_cut = d_cut
         self._d_pending = None
         # overlap_wgrad: the weight gradients of a backward pass run on a second stream beside its chain of input gradients
-        # (ops.Runtime.weight_grads_on); same values, the parameters' .grad are complete when backward() returns.  Off by
-        # default: measured neutral under hipGraph replay (12.76 vs 12.74 ms at config 2 - the fork/join branches of one
-        # captured graph do not run side by side) and slower eagerly (more host work per layer)
+        # (ops.Runtime.weight_grads_on); same values, the parameters' .grad are complete when backward() returns.  Measured
+        # neutral under hipGraph replay while the step's kernels were larger (12.76 vs 12.74 ms at config 2), -0.25 ms
+        # (11.24 -> 10.99) since the small contractions got their own kernels and leave most of the chip idle: bench.py
+        # turns it on for single-GPU runs.  Off by default here: slower eagerly (more host work per layer), and the
+        # data-parallel reducer's hooks do not see gradients that bypass autograd's accumulation.
         self.overlap_wgrad = bool(overlap_wgrad)
         self._wgrad_side = None
         # stacked_d: the D-step's three discriminator passes (real / fake / augmented) run as ONE pass over a [3B] batch
