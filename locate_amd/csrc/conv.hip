@@ -1186,7 +1186,7 @@ static void launch_pointwise_px(const IgParams& p, hipStream_t st) {
 
 static void launch_pointwise(const IgParams& p, hipStream_t st) {
     // two pixels per thread only when that still leaves >= 4 blocks per CU
-    if ((long long)p.B * p.H * p.W >= 2ll * 256 * 1024) launch_pointwise_px<2>(p, st);
+    if ((long long)p.B * p.H * p.W >= (long long)knob_int("LOCATE_PX2_MIN", 2 * 256 * 1024)) launch_pointwise_px<2>(p, st);
     else launch_pointwise_px<1>(p, st);
 }
 

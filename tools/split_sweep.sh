@@ -1,2 +1,4 @@
-S="--shape convT,768,384,1,1,0,8,64 --shape convT,384,192,1,1,0,16,64 --shape conv,192,192,1,1,0,16,64 --shape conv,256,256,5,2,2,4,192 --shape conv,128,128,5,2,2,8,192 --shape conv,64,64,5,2,2,16,192 --shape conv,512,512,5,2,2,2,192 --shape conv,256,256,5,2,2,4,64 --shape conv,128,128,5,2,2,8,64 --shape conv,256,256,1,1,0,4,192"
-for k in 64 4 3 2 1; do echo "KS_MAX=$k"; LOCATE_HIP_DEBUG_LIBRARY=1 LOCATE_KS_MAX=$k python tools/bench_conv.py --reps 30 $S 2>/dev/null | grep -v "^stage"; done
+#!/bin/bash
+# debug-library sweeps of the eight-wave threshold (LOCATE_W8_MAX) and the split cap (LOCATE_KS_MAX) on chosen shapes
+S=${SHAPES:-"--shape convT,768,768,4,2,1,4,64 --shape convT,384,384,4,2,1,8,64 --shape convT,192,192,4,2,1,16,64 --shape convT,96,96,4,2,1,32,64 --shape conv,48,48,3,1,1,64,64"}
+for m in ${W8:-320 4096}; do for k in ${KS:-64}; do echo "W8_MAX=$m KS_MAX=$k"; LOCATE_HIP_DEBUG_LIBRARY=1 LOCATE_W8_MAX=$m LOCATE_KS_MAX=$k python tools/bench_conv.py --reps 30 $S 2>/dev/null | grep -v "^stage"; done; done
