@@ -55,6 +55,9 @@ def time_it(fn, reps):
     return e0.elapsed_time(e1) / (3 * reps)
 
 
+ZEROS = False          # --zeros: all-zero operands (the chip holds a higher clock on them: separates clock-bound from issue-bound)
+
+
 def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, use_cnt=True, dev=None):
     """(ms forward, ms input gradient, ms weight gradient, algorithmic FLOPs, bytes forward) of one layer through the C ABI."""
     dev = dev or torch.device("cuda:0")
@@ -64,10 +67,15 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
     wshape = (cout, cin, kh, kw) if kind == "conv" else (cin, cout, kh, kw)
     w = torch.randn(wshape, device=dev) * 0.05
     x = torch.randn(B, cin, H, W, device=dev)
+    if ZEROS:
+        w.zero_()
+        x.zero_()
     geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
     garr = (ctypes.c_int * 12)(*geom)
     y = torch.empty(out_shape, device=dev)
     gy = torch.randn(out_shape, device=dev)
+    if ZEROS:
+        gy.zero_()
     gx = torch.empty_like(x)
     gw = torch.empty_like(w)
     one = torch.ones(1, device=dev)
@@ -112,7 +120,10 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="bf16 operands (precision 1) instead of the fp32-faithful splits")
     ap.add_argument("--no-counters", action="store_true", help="NULL arrival counters: split-K partial tiles summed by the reduction kernel")
     ap.add_argument("--shape", action="append", default=[], help="extra stage: kind,Cin,Cout,k,stride,pad,H,B (replaces the list)")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands")
     args = ap.parse_args()
+    global ZEROS
+    ZEROS = args.zeros
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
     shapes = SHAPES
