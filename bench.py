@@ -129,7 +129,12 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
            "traffic": None if traffic is None else round(traffic), "traffic_source": source,
            "algorithmic_bytes": round(alg_bytes), "per_stage": rows}
     if not bf16:
-        out.update({"executed_bf16_mfma_tflops": round(6 * achieved, 1), "bf16_dense_peak": 2500.0, "fp32_mfma_peak": 157.3})
+        out.update({"executed_bf16_mfma_tflops": round(6 * achieved, 1), "bf16_dense_peak": 2500.0, "fp32_mfma_peak": 157.3,
+                    # what a bare bf16 MFMA loop sustains on RANDOM operands (the chip lowers its clock under matrix load:
+                    # MI355X_MICROARCH.md "DVFS give-back" measures 1247 TF there, 1483 on zeros); `frac` above stays against
+                    # the nominal peak, this is the same figure against that ceiling (profiles/r02_patch_form_ab.txt: these
+                    # launches run 15-18 % faster on all-zero operands - they are clock-bound)
+                    "sustained_bf16_mfma_on_random_data": 1247.0, "frac_of_sustained": round(6 * achieved / 1247.0, 4)})
     return out
 
 
