@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="weight gradients in line with the backward pass (default on one GPU: on a second stream beside it; "
                          "same values, -0.25 ms per step since the small launches stopped filling the chip)")
+    ap.add_argument("--dp-wgrad-overlap", action="store_true",
+                    help="also with --gpus N > 1 (correct - tests/test_gpu_dp.py - but unmeasured on RCCL: the only rehearsal "
+                         "possible here, two gloo ranks time-slicing ONE GPU, runs 17x slower with it, 3.3 s vs 0.19 s per step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the G-step's generator pass in line instead of on a second stream beside the D-step")
     return ap.parse_args()
@@ -292,7 +295,8 @@ def main():
         red_g = GradAllReducer(G.parameters())
         red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None)
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
-                     overlap_wgrad=(world == 1 and not args.no_wgrad_overlap), d_cut=d_cut if world > 1 else None)
+                     overlap_wgrad=(world == 1 and not args.no_wgrad_overlap) or args.dp_wgrad_overlap,
+                     d_cut=d_cut if world > 1 else None)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)

@@ -132,7 +132,10 @@ class GradAllReducer:
 
     def _make_hook(self, i):
         def hook(p):
-            if not self._active or i in self._seen:
+            # (the hook also fires when autograd reaches a parameter with an UNDEFINED gradient - e.g. the weights whose
+            # gradients TrainStep(overlap_wgrad=True) produces on a second stream and assigns at the end of the pass: such a
+            # parameter has nothing to send yet; finish() picks it up)
+            if not self._active or i in self._seen or p.grad is None:
                 return
             self._seen.add(i)
             b = self.bucket_of[i]

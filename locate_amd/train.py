@@ -55,13 +55,10 @@ class TrainStep:
         # (ops.Runtime.weight_grads_on); same values, the parameters' .grad are complete when backward() returns.  Measured
         # neutral under hipGraph replay while the step's kernels were larger (12.76 vs 12.74 ms at config 2), -0.25 ms
         # (11.24 -> 10.99) since the small contractions got their own kernels and leave most of the chip idle: bench.py
-        # turns it on for single-GPU runs.  Off by default here: slower eagerly (more host work per layer), and the
-        # data-parallel reducer's hooks do not see gradients that bypass autograd's accumulation.
+        # turns it on.  Off by default here: slower eagerly (more host work per layer).  With a data-parallel reducer the
+        # gradients that bypass autograd's accumulation are exchanged by the reducer's finish() (eager) or by the segment's
+        # launch_group() (graph replay) - tests/test_gpu_dp.py runs both forms with the flag on.
         self.overlap_wgrad = bool(overlap_wgrad)
-        if self.overlap_wgrad and (reducer_g is not None or reducer_d is not None):
-            # measured: a 2-rank run with both produced un-averaged weight gradients (tests/test_gpu_dp.py with the flag on)
-            raise ValueError("overlap_wgrad is a single-GPU option: the data-parallel reducer exchanges gradients as autograd "
-                             "accumulates them, and weight gradients on the second stream bypass that accumulation")
         self._wgrad_side = None
         # stacked_d: the D-step's three discriminator passes (real / fake / augmented) run as ONE pass over a [3B] batch
         # with per-call InPlaceNorm statistics and per-call spectral-norm sigma (three power iterations up front, in the

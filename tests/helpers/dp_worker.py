@@ -3,7 +3,8 @@ rank (both ranks on cuda:0, gloo backend - RCCL refuses two ranks on one device;
 segmented backward and the side-stream exchange are the same).  argv: rank world port golden out_path mode
 mode = "eager": one step of the tiny g8 network on this rank's shard through TrainStep + GradAllReducer; records the
 averaged gradients the optimizers saw.  mode = "graph": two eager + `replays` graph-replayed steps; mode = "eager4": the same
-number of steps eagerly.  Both record the final parameters."""
+number of steps eagerly.  Both record the final parameters.  A "+wg" suffix: the weight gradients on a second stream
+(TrainStep(overlap_wgrad=True)) - they reach `.grad` through an end-of-backward callback, not through autograd's accumulation."""
 import os
 import sys
 
@@ -17,6 +18,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, golden, out_path, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
+    overlap_wgrad = mode.endswith("+wg")
+    mode = mode.split("+")[0]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from locate_amd import Discriminator, Generator, Nadam, NetConfig, TrainStep
@@ -41,7 +44,8 @@ def main():
     red_g = GradAllReducer(G.parameters(), bucket_bytes=64 << 10)          # small buckets: several per network
     red_d = GradAllReducer(D.parameters(), bucket_bytes=64 << 10, late=late_v, groups=D.segment_parameters(d_cut))
     step = TrainStep(G, D, Nadam(G.parameters(), lr=cfg.glr, betas=(cfg.beta1, cfg.beta2)),
-                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), reducer_g=red_g, reducer_d=red_d, d_cut=d_cut)
+                     Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), reducer_g=red_g, reducer_d=red_d, d_cut=d_cut,
+                     overlap_wgrad=overlap_wgrad)
     B = z["step1/latent"].shape[0]
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = [T(z["step1/" + k])[lo:hi].to(dev) for k in ("latent", "real", "aug")]

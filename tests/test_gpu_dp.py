@@ -79,9 +79,10 @@ def _oracle_shard_means(z, world=2):
     return d_mean, mean(g_grads), sum(losses) / world
 
 
-def test_dp_gradients_equal_mean_of_reference_shard_gradients(tmp_path):
+@pytest.mark.parametrize("suffix", ["", "+wg"])
+def test_dp_gradients_equal_mean_of_reference_shard_gradients(tmp_path, suffix):
     z = load_golden("g8_tiny_e2e")
-    recs = _run_ranks(tmp_path, "eager")
+    recs = _run_ranks(tmp_path, "eager" + suffix)
     d_want, g_want, d_loss = _oracle_shard_means(z)
     nb_d, nb_g, groups = recs[0]["buckets"]
     assert nb_d >= 3 and nb_g >= 2 and groups == 2             # several buckets per net, two segment groups for D
@@ -99,9 +100,10 @@ def test_dp_gradients_equal_mean_of_reference_shard_gradients(tmp_path):
     assert abs(mean_loss - d_loss) <= 2e-5 * max(abs(d_loss), 1.0)
 
 
-def test_dp_graph_replay_with_segmented_backward_equals_eager(tmp_path):
+@pytest.mark.parametrize("suffix", ["", "+wg"])
+def test_dp_graph_replay_with_segmented_backward_equals_eager(tmp_path, suffix):
     eager = _run_ranks(tmp_path, "eager4")
-    graph = _run_ranks(tmp_path, "graph")
+    graph = _run_ranks(tmp_path, "graph" + suffix)
     for net in ("G", "D"):
         for k, v in graph[0][net].items():
             assert torch.equal(v, graph[1][net][k]), ("replicas diverged under graph replay", net, k)

@@ -281,13 +281,3 @@ def test_networks_do_not_share_runtime_state():
     assert all(m.runtime is D3.runtime for m in D3.modules() if isinstance(m, (InPlaceNorm, SpectralNorm)))
     assert SpectralNorm(torch.nn.Conv2d(3, 4, 1)).runtime is None            # stand-alone layer: the default runtime at call time
 
-
-def test_weight_gradient_stream_is_rejected_together_with_a_reducer():
-    """TrainStep(overlap_wgrad=True) hands weight gradients to `.grad` from an end-of-backward callback; a GradAllReducer
-    watches autograd's accumulation.  The combination is refused instead of silently exchanging stale gradients."""
-    import pytest
-    from locate_amd import TrainStep
-    from locate_amd.parallel import GradAllReducer
-    p = torch.nn.Parameter(torch.zeros(3))
-    with pytest.raises(ValueError, match="single-GPU"):
-        TrainStep(None, None, None, None, reducer_g=GradAllReducer([p]), overlap_wgrad=True)
