@@ -281,3 +281,38 @@ def test_networks_do_not_share_runtime_state():
     assert all(m.runtime is D3.runtime for m in D3.modules() if isinstance(m, (InPlaceNorm, SpectralNorm)))
     assert SpectralNorm(torch.nn.Conv2d(3, 4, 1)).runtime is None            # stand-alone layer: the default runtime at call time
 
+
+
+def test_fork_gradient_protocol_on_plain_tensors():
+    """ops.fork is pure autograd plumbing (no kernel): two consumers that know nothing about the slot get the ordinary sum;
+    two that claim the slot's buffer and return it (the second adding into it) are not added a second time; under no_grad
+    the fork is the identity."""
+    from locate_amd import ops
+    x = torch.randn(5, 3, requires_grad=True)
+    a, b = ops.fork(x * 1.0)
+    (a.sin().sum() + (2.0 * b).sum()).backward()
+    torch.testing.assert_close(x.grad, x.detach().cos() + 2.0)
+
+    class Claims(torch.autograd.Function):           # stands for a kernel with an `accumulate` flag
+        @staticmethod
+        def forward(ctx, t, factor, slot):
+            ctx.factor, ctx.slot = factor, slot
+            return t * factor
+
+        @staticmethod
+        def backward(ctx, g):
+            buf, acc = ctx.slot.claim(g)
+            if acc:
+                buf.add_(g * ctx.factor)
+            else:
+                buf.copy_(g * ctx.factor)
+            return buf, None, None
+
+    y = torch.randn(4, 2, requires_grad=True)
+    a, b = ops.fork(y * 1.0)
+    assert a._locate_slot is b._locate_slot
+    (Claims.apply(a, 3.0, a._locate_slot).sum() + Claims.apply(b, 5.0, b._locate_slot).sum()).backward()
+    torch.testing.assert_close(y.grad, torch.full_like(y, 8.0))
+    with torch.no_grad():
+        u, v = ops.fork(y)
+    assert u is y and v is y
