@@ -259,7 +259,10 @@ def test_step_vs_oracle_on_unusual_shapes(S, B, ff, stacked, switches):
     DO.step, GO.step = d_hook, g_hook
     out = step(latent.to(dev), real.to(dev), aug.to(dev))
     for k in ("generated", "fake", "d_true", "d_gen", "d_error", "penalty", "g_error"):
-        assert_close(out[k].detach().cpu().reshape(want[k].shape), want[k], 3e-5, k)
+        # the consistency penalty squares the DIFFERENCE of two discriminator outputs (grad_penalty.py:2-3): their 1e-5-level
+        # deviations do not cancel in it (measured 2.1e-5 ... 3.0e-5 across this test's cases, and the oracle side of the
+        # comparison is a CPU run whose BLAS differs from host to host) - it gets 1e-4, everything else 3e-5
+        assert_close(out[k].detach().cpu().reshape(want[k].shape), want[k], 1e-4 if k == "penalty" else 3e-5, k)
     for tag, got, ref in (("D", rec["d"], want["d_grads"]), ("G", rec["g"], want["g_grads"])):
         assert sorted(got) == sorted(ref), tag
         for k, v in ref.items():
