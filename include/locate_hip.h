@@ -76,6 +76,9 @@ int locate_gate_fwd(const float* x, const float* a, int a_per_plane, const float
 int locate_gate_fwd_stats(const float* x, const float* a, int a_per_plane, const float* gamma, float* out, int64_t planes,
                           int hw, int groups, double* stats_partial, void* stream);
 size_t locate_gate_bwd_workspace_bytes(int64_t planes);
+/* dgamma nullable: the kernel then only leaves its locate_gate_bwd_partials(planes, hw) block sums (doubles, at the start of
+ * `workspace`; dgamma = their sum in index order) for the caller to add up - see locate_fin_sums - or to ignore */
+int locate_gate_bwd_partials(int64_t planes, int hw);
 int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g, float* dx, float* da,
                     float* dgamma, int64_t planes, int hw, void* workspace, int accumulate_dx,
                     void* stream);
@@ -196,6 +199,24 @@ int locate_groupdot_dgrad(const float* gy, const float* w, const float* scale, i
 int locate_groupdot_wgrad_partials(int G, int L);
 int locate_groupdot_wgrad(const float* x, int64_t x_bs, const float* gy, float* gw, const float* w_ref, const float* inv_scale,
                           int scale_group_batch, int scale_stride, double* inner_partial, int B, int G, int L, void* stream);
+
+/* ---- end-of-backward finalisers, batched over all layers of a backward pass (finalise.hip): what only feeds PARAMETER
+ *      gradients - spectral norm's rank-1 term with du / dsigma (libs/spectral_norm.py:31-32 under autograd), the stacked
+ *      calls' <gy_k, y_k - bias>, the gates' dgamma sums (libs/merge.py:33-38) - in one launch per kind instead of two or
+ *      three small launches per layer.  `records`: HOST array of n records of locate_fin_record_bytes() = 112 bytes
+ *      { const void* p[8]; int64 l[2]; int32 i[8]; } passed on BY VALUE in the kernel arguments (no device table):
+ *        dots : p = {gy, y, bias|0, partial out [groups][np]}, l = {gy_bs, y_bs}, i = {groups, Bg, M, plane};
+ *               np = locate_fin_sn_dot_partials(Bg, M, plane)
+ *        rank1: p = {partial (double), sigma table, u, v, wv, gw (in/out), du|0, dsigma_out|0}, l = {wv_stride},
+ *               i = {npartial per call, groups (0 = one call: locate_sn_weight_bwd's arithmetic; k >= 1 = stacked:
+ *               locate_sn_weight_bwd_grouped's), sigma_stride, h, wd}
+ *        sums : p = {partials (double), out (float)}, i = {count}
+ *      Same arithmetic and summation order as the per-layer entry points: bit-identical results. ---- */
+size_t locate_fin_record_bytes(void);
+int locate_fin_sn_dot_partials(int Bg, int M, int plane);
+int locate_fin_sn_dots(const void* records, int n, void* stream);
+int locate_fin_sn_rank1(const void* records, int n, void* stream);
+int locate_fin_sums(const void* records, int n, void* stream);
 
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */

@@ -84,6 +84,12 @@ PROTOTYPES = {
     "locate_groupdot_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "locate_groupdot_wgrad_partials": (c_i, [c_i, c_i]),
     "locate_groupdot_wgrad": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
+    "locate_fin_record_bytes": (c_sz, []),
+    "locate_fin_sn_dot_partials": (c_i, [c_i, c_i, c_i]),
+    "locate_fin_sn_dots": (c_i, [c_p, c_i, c_p]),
+    "locate_fin_sn_rank1": (c_i, [c_p, c_i, c_p]),
+    "locate_fin_sums": (c_i, [c_p, c_i, c_p]),
+    "locate_gate_bwd_partials": (c_i, [c_i64, c_i]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
     "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),
@@ -94,6 +100,11 @@ PROTOTYPES = {
 
 class LocateError(RuntimeError):
     pass
+
+
+# bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
+# exports every NAME would otherwise be called with shifted arguments
+EXPECTED_ABI = 4
 
 
 _lib = None
@@ -111,6 +122,10 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        got = handle.locate_abi_version()
+        if got != EXPECTED_ABI:
+            raise LocateError("%s reports ABI version %d, this package binds version %d: rebuild it (`python -m locate_amd.build`)"
+                              % (LIB_PATH, got, EXPECTED_ABI))
         _lib = handle
     return _lib
 

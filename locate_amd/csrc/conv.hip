@@ -2438,7 +2438,12 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         return LOCATE_OK;
     }
     const PwPlan pq = pw_plan(g);
-    if (pq.ok && (x_bs & 3) == 0 && (gy_bs & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
+    if (pq.ok) {
+        // the size queries (workspace bytes, partial count) decide on the geometry alone, so the pointwise plan is binding here:
+        // operands it cannot take are an error, never a silent switch to the general plan with its different workspace layout
+        LOCATE_REQUIRE((x_bs & 3) == 0 && (gy_bs & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
+                       "locate_conv_wgrad: narrow 1x1 layers need 16-byte aligned x / gy and batch strides that are multiples of 4");
         LOCATE_REQUIRE(workspace, "locate_conv_wgrad: the split reduction needs a workspace");
         PwParams q;
         q.x = x; q.gy = gy; q.slab = static_cast<float*>(workspace); q.x_bs = x_bs; q.gy_bs = gy_bs;

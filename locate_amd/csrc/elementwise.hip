@@ -328,6 +328,13 @@ LOCATE_API int locate_gate_fwd_stats(const float* x, const float* a, int a_per_p
 
 LOCATE_API size_t locate_gate_bwd_workspace_bytes(int64_t planes) { (void)planes; return 4096 * sizeof(double); }
 
+static int64_t gate_bwd_blocks(int64_t planes, int hw) {
+    int64_t blocks = hw >= 1024 ? planes : cdiv64(planes, 4);
+    return blocks > 4096 ? 4096 : blocks;
+}
+// how many doubles locate_gate_bwd leaves at the start of its workspace: their sum (in index order) is dgamma
+LOCATE_API int locate_gate_bwd_partials(int64_t planes, int hw) { return (int)gate_bwd_blocks(planes, hw); }
+
 // da: [planes*hw] when a_per_plane == 0, [planes] otherwise.  dgamma: one float (overwritten).
 // (Tried and dropped: the kernel's last-arriving block reducing dgamma itself instead of the second launch - up to 4096
 // blocks taking a ticket from ONE counter serialise at ~90 arrivals per microsecond: +0.7 ms per training step.)
@@ -337,8 +344,7 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
     double* block_x2g = static_cast<double*>(workspace);
     const bool whole_block = hw >= 1024;
-    int64_t blocks = whole_block ? planes : cdiv64(planes, 4);
-    if (blocks > 4096) blocks = 4096;
+    const int64_t blocks = gate_bwd_blocks(planes, hw);
     if (whole_block)
         gate_bwd_plane_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
@@ -348,6 +354,7 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
                                                                             a_per_plane, accumulate_dx);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
+    if (!dgamma) return LOCATE_OK;       // the caller sums the locate_gate_bwd_partials() doubles in `workspace` itself, or needs none
     gate_bwd_final_kernel<<<1, 256, 0, as_stream(stream)>>>(block_x2g, dgamma, (int)blocks);
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(final)");
     return LOCATE_OK;

@@ -1,0 +1,211 @@
+// End-of-backward finalisers, batched: what every spectral-normalised layer and every residual gate still owes its
+// parameters' gradients once the backward pass's last data gradient is out -
+//     * <gy_k, y_k - bias> per stacked call k            (activation-side <G_k, W_bar>, spectral.hip)
+//     * dW_bar += (sum_k dsigma_k) u v^T, du, dsigma     (rank-1 term of d(W_bar / sigma), libs/spectral_norm.py:31-32)
+//     * dgamma = sum of the gate kernel's block partials (libs/merge.py:33-38)
+// - for ALL layers of the pass in one launch each, instead of two or three small launches per layer in the middle of the
+// pass's dependent chain (84 + 34 of the ~870 launches of a step at 64x64).
+//
+// The records travel BY VALUE in the kernel arguments (<= FIN_MAX records of 112 bytes per launch): no device table, no
+// host-to-device copy - the operands are this pass's transient gradient buffers, whose addresses differ from pass to pass,
+// and a hipGraph capture records the arguments themselves.  Arithmetic and summation order are those of the per-layer
+// kernels (spectral.hip, elementwise.hip): results are bit-identical to the unbatched path, which the data-parallel eager
+// mode still takes (its reducer hooks need complete gradients from autograd).
+#include "common.h"
+
+#define FIN_MAX 32
+struct FinRec {
+    const void* p[8];
+    long long l[2];
+    int i[8];
+};
+struct FinBatch {
+    FinRec r[FIN_MAX];
+};
+
+LOCATE_API size_t locate_fin_record_bytes(void) { return sizeof(FinRec); }
+
+// ---- activation-side dots of stacked calls -------------------------------------------------------------------------
+// p0 gy, p1 y, p2 bias (nullable), p3 partial out [groups][nb];  l0 gy_bs, l1 y_bs;  i0 groups, i1 Bg, i2 M, i3 plane, i4 nb
+#define FIN_DOT_CHUNK 4096
+#define FIN_DOT_BLOCKS 256
+__global__ void __launch_bounds__(256) fin_sn_dots_kernel(const FinBatch batch) {
+    __shared__ double scratch[16];
+    const FinRec& R = batch.r[blockIdx.y >> 2];
+    const int grp = blockIdx.y & 3;
+    const int groups = R.i[0], Bg = R.i[1], M = R.i[2], plane = R.i[3], nb = R.i[4];
+    if (grp >= groups || (int)blockIdx.x >= nb) return;
+    const float* __restrict__ gy = static_cast<const float*>(R.p[0]);
+    const float* __restrict__ y = static_cast<const float*>(R.p[1]);
+    const float* __restrict__ bias = static_cast<const float*>(R.p[2]);
+    double* __restrict__ partial = static_cast<double*>(const_cast<void*>(R.p[3]));
+    const int64_t gy_bs = R.l[0], y_bs = R.l[1];
+    const int per_b = M * plane;
+    const int nchunk = (per_b + FIN_DOT_CHUNK - 1) / FIN_DOT_CHUNK;
+    const int work = Bg * nchunk;
+    const bool vec = (plane & 3) == 0 && (gy_bs & 3) == 0 && (y_bs & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    double acc = 0.0;
+    for (int w = blockIdx.x; w < work; w += nb) {
+        const int bl = w / nchunk, ch = w - bl * nchunk;
+        const int64_t b = (int64_t)grp * Bg + bl;
+        const float* gp = gy + b * gy_bs;
+        const float* yp = y + b * y_bs;
+        const int j0 = ch * FIN_DOT_CHUNK, j1 = min(j0 + FIN_DOT_CHUNK, per_b);
+        float part = 0.0f;
+        if (vec) {
+            for (int j = j0 + 4 * (int)threadIdx.x; j < j1; j += 1024) {
+                const float bv = bias ? bias[j / plane] : 0.0f;
+                const float4 g4 = *reinterpret_cast<const float4*>(gp + j), y4 = *reinterpret_cast<const float4*>(yp + j);
+                part += (g4.x * (y4.x - bv) + g4.y * (y4.y - bv)) + (g4.z * (y4.z - bv) + g4.w * (y4.w - bv));
+            }
+        } else {
+            for (int j = j0 + (int)threadIdx.x; j < j1; j += 256) part = fmaf(gp[j], yp[j] - (bias ? bias[j / plane] : 0.0f), part);
+        }
+        acc += (double)part;
+    }
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) partial[(int64_t)grp * nb + blockIdx.x] = acc;
+}
+
+// ---- rank-1 term, du, dsigma ------------------------------------------------------------------------------------------
+// p0 partial (double), p1 sigma table ({sigma, 1/sigma} pairs), p2 u, p3 v, p4 wv, p5 gw (in/out), p6 du (nullable),
+// p7 dsigma out (nullable);  l0 wv_stride;  i0 npartial (per group), i1 groups (0: one un-stacked call, dsigma from the
+// weight-side partials = -sum / sigma^2; k >= 1: stacked, dsigma_k = -sum_k / sigma_k), i2 sigma_stride, i3 h, i4 wd,
+// i5 first block of this record in the launch, i6 its block count
+__global__ void __launch_bounds__(256) fin_sn_rank1_kernel(const FinBatch batch, int n_rec) {
+    __shared__ double scratch[16];
+    int ri = 0;
+    for (int k = 1; k < n_rec; ++k)
+        if ((int)blockIdx.x >= batch.r[k].i[5]) ri = k;
+    const FinRec& R = batch.r[ri];
+    const int bx = (int)blockIdx.x - R.i[5], nblk = R.i[6];
+    const double* __restrict__ partial = static_cast<const double*>(R.p[0]);
+    const float* __restrict__ sigma_tab = static_cast<const float*>(R.p[1]);
+    const float* __restrict__ u = static_cast<const float*>(R.p[2]);
+    const float* __restrict__ v = static_cast<const float*>(R.p[3]);
+    const float* __restrict__ wv = static_cast<const float*>(R.p[4]);
+    float* __restrict__ gw = static_cast<float*>(const_cast<void*>(R.p[5]));
+    float* __restrict__ du = static_cast<float*>(const_cast<void*>(R.p[6]));
+    float* __restrict__ dsigma_out = static_cast<float*>(const_cast<void*>(R.p[7]));
+    const int npartial = R.i[0], groups = R.i[1], sigma_stride = R.i[2], h = R.i[3], wd = R.i[4];
+    const int64_t wv_stride = R.l[0];
+    float dsg[4] = {0.f, 0.f, 0.f, 0.f};
+    float total = 0.0f;
+    if (groups == 0) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[i];
+        acc = block_sum<double>(acc, scratch);
+        const float sg = sigma_tab[0];
+        dsg[0] = (float)(-acc / ((double)sg * (double)sg));
+        total = dsg[0];
+    } else {
+        for (int k = 0; k < groups; ++k) {
+            double acc = 0.0;
+            for (int i = threadIdx.x; i < npartial; i += blockDim.x) acc += partial[(int64_t)k * npartial + i];
+            acc = block_sum<double>(acc, scratch);
+            dsg[k] = (float)(-acc * (double)sigma_tab[k * sigma_stride + 1]);     // [k][1] = 1 / sigma_k
+            total += dsg[k];
+        }
+    }
+    const int64_t n = (int64_t)h * wd;
+    const int64_t stride = (int64_t)nblk * blockDim.x;
+    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
+        gw[i] = fmaf(total * u[r], v[c], gw[i]);
+    }
+    if (bx == 0) {
+        if (du) {
+            const int ng = groups == 0 ? 1 : groups;
+            for (int i = threadIdx.x; i < h; i += blockDim.x) {
+                if (groups == 0) {
+                    du[i] = dsg[0] * wv[i];
+                } else {
+                    float a = 0.0f;
+                    for (int k = 0; k < ng; ++k) a = fmaf(dsg[k], wv[(int64_t)k * wv_stride + i], a);
+                    du[i] = a;
+                }
+            }
+        }
+        if (threadIdx.x == 0 && dsigma_out) dsigma_out[0] = total;
+    }
+}
+
+// ---- plain sums of double partials into one float (the gates' dgamma) ---------------------------------------------------
+// p0 partials (double), p1 out (float);  i0 count
+__global__ void __launch_bounds__(256) fin_sums_kernel(const FinBatch batch) {
+    __shared__ double scratch[16];
+    const FinRec& R = batch.r[blockIdx.x];
+    const double* __restrict__ part = static_cast<const double*>(R.p[0]);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < R.i[0]; i += blockDim.x) acc += part[i];
+    acc = block_sum<double>(acc, scratch);
+    if (threadIdx.x == 0) static_cast<float*>(const_cast<void*>(R.p[1]))[0] = (float)acc;
+}
+
+// number of partial sums per stacked call that locate_fin_sn_dots writes for a layer output of Bg x M x plane per call
+LOCATE_API int locate_fin_sn_dot_partials(int Bg, int M, int plane) {
+    const int64_t work = (int64_t)Bg * (((int64_t)M * plane + FIN_DOT_CHUNK - 1) / FIN_DOT_CHUNK);
+    return work < FIN_DOT_BLOCKS ? (int)work : FIN_DOT_BLOCKS;
+}
+
+static int fin_blocks_for(int64_t n) { return stream_grid(n, 1024); }
+
+// `records`: HOST array of n FinRec (layouts above; i[4] of a dots record and i[5], i[6] of a rank-1 record are filled in
+// here).  Any n: the launches take FIN_MAX records each.
+LOCATE_API int locate_fin_sn_dots(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0, "locate_fin_sn_dots: bad arguments");
+    const FinRec* rec = static_cast<const FinRec*>(records);
+    for (int at = 0; at < n; at += FIN_MAX) {
+        FinBatch b = {};
+        const int m = n - at < FIN_MAX ? n - at : FIN_MAX;
+        for (int k = 0; k < m; ++k) {
+            b.r[k] = rec[at + k];
+            FinRec& R = b.r[k];
+            LOCATE_REQUIRE(R.p[0] && R.p[1] && R.p[3] && R.i[0] >= 1 && R.i[0] <= 4 && R.i[1] > 0 && R.i[2] > 0 && R.i[3] > 0 &&
+                           (int64_t)R.i[2] * R.i[3] < (1ll << 31), "locate_fin_sn_dots: bad record %d", at + k);
+            R.i[4] = locate_fin_sn_dot_partials(R.i[1], R.i[2], R.i[3]);
+        }
+        fin_sn_dots_kernel<<<dim3(FIN_DOT_BLOCKS, 4 * m), 256, 0, as_stream(stream)>>>(b);
+        LOCATE_LAUNCH_CHECK("locate_fin_sn_dots");
+    }
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_fin_sn_rank1(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0, "locate_fin_sn_rank1: bad arguments");
+    const FinRec* rec = static_cast<const FinRec*>(records);
+    for (int at = 0; at < n; at += FIN_MAX) {
+        FinBatch b = {};
+        const int m = n - at < FIN_MAX ? n - at : FIN_MAX;
+        int blocks = 0;
+        for (int k = 0; k < m; ++k) {
+            b.r[k] = rec[at + k];
+            FinRec& R = b.r[k];
+            LOCATE_REQUIRE(R.p[0] && R.p[1] && R.p[2] && R.p[3] && R.p[5] && R.i[0] > 0 && R.i[1] >= 0 && R.i[1] <= 4 && R.i[3] > 0 &&
+                           R.i[4] > 0 && (!R.p[6] || R.p[4]), "locate_fin_sn_rank1: bad record %d", at + k);
+            R.i[5] = blocks;
+            R.i[6] = fin_blocks_for((int64_t)R.i[3] * R.i[4]);
+            blocks += R.i[6];
+        }
+        fin_sn_rank1_kernel<<<blocks, 256, 0, as_stream(stream)>>>(b, m);
+        LOCATE_LAUNCH_CHECK("locate_fin_sn_rank1");
+    }
+    return LOCATE_OK;
+}
+
+LOCATE_API int locate_fin_sums(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0, "locate_fin_sums: bad arguments");
+    const FinRec* rec = static_cast<const FinRec*>(records);
+    for (int at = 0; at < n; at += FIN_MAX) {
+        FinBatch b = {};
+        const int m = n - at < FIN_MAX ? n - at : FIN_MAX;
+        for (int k = 0; k < m; ++k) {
+            b.r[k] = rec[at + k];
+            LOCATE_REQUIRE(b.r[k].p[0] && b.r[k].p[1] && b.r[k].i[0] > 0, "locate_fin_sums: bad record %d", at + k);
+        }
+        fin_sums_kernel<<<m, 256, 0, as_stream(stream)>>>(b);
+        LOCATE_LAUNCH_CHECK("locate_fin_sums");
+    }
+    return LOCATE_OK;
+}

@@ -134,13 +134,23 @@ class Runtime:
         self._dv_tables = {}             # tuple of addresses -> (device table, max_h, max_wd)
         self._end_scheduled = False
         self._side = None                # side stream with work of the running backward pass on it
-        self._side_results = []          # (parameter, gradient produced on the side stream)
-        self._keep = []                  # operands of side-stream kernels: alive until the join
+        self._side_results = []          # (parameter, gradient assigned at the end of the pass instead of through autograd)
+        self._keep = []                  # operands of side-stream / deferred kernels: alive until the end of the pass
+        # defer_finalisers: the small per-layer launches that only feed PARAMETER gradients - the spectral-norm rank-1 term
+        # with du / dsigma, the stacked calls' activation-side dots, the gates' d(gamma) sums - are queued and run once per
+        # backward pass, for all layers in one launch each (csrc/finalise.hip), from the end-of-pass callback; those
+        # gradients are then assigned to .grad there instead of travelling through autograd.  Off: every layer finishes its
+        # own gradients inside its backward node (what a data-parallel reducer's post-accumulate hooks need).
+        self.defer_finalisers = True
+        self._fin_dots = []              # packed FinRec records (csrc/finalise.hip)
+        self._fin_rank1 = []
+        self._fin_sums = []
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
     def __deepcopy__(self, memo):
         rt = Runtime()
         rt.precision = self.precision
+        rt.defer_finalisers = self.defer_finalisers
         return rt
 
     def stacked_calls(self, n):
@@ -149,6 +159,9 @@ class Runtime:
     def weight_grads_on(self, stream):
         return _OnStream(self, stream)
 
+    def finalisers_deferred(self, on):
+        return _Deferral(self, on)
+
     def reset(self):
         """Forget whatever an aborted backward pass left behind (an exception inside the autograd engine never runs its
         callbacks); the step driver calls this before every backward()."""
@@ -156,6 +169,7 @@ class Runtime:
         self._side = None
         self._side_results = []
         self._keep = []
+        self._fin_dots, self._fin_rank1, self._fin_sums = [], [], []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
         self._dv_layers = {}
@@ -171,14 +185,52 @@ class Runtime:
         side, self._side = self._side, None
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-            results, self._side_results = self._side_results, []
-            self._keep = []
-            for param, grad in results:
-                if param.grad is None:
-                    param.grad = grad
-                else:
-                    param.grad.add_(grad)
+        # the queued finalisers, one launch per kind for the whole pass; the rank-1 launch also fills the dsigma slots the
+        # batched dv below reads
+        L = lib()
+        st = _stream()
+        for queue, fn, name in ((self._fin_dots, L.locate_fin_sn_dots, "locate_fin_sn_dots"),
+                                (self._fin_rank1, L.locate_fin_sn_rank1, "locate_fin_sn_rank1"),
+                                (self._fin_sums, L.locate_fin_sums, "locate_fin_sums")):
+            if queue:
+                blob = b"".join(queue)
+                check(fn(blob, len(queue), st), name)
+        self._fin_dots, self._fin_rank1, self._fin_sums = [], [], []
+        results, self._side_results = self._side_results, []
+        self._keep = []
+        for param, grad in results:
+            if param.grad is None:
+                param.grad = grad
+            else:
+                param.grad.add_(grad)
         self._finalize_dv()
+
+    _FIN = __import__("struct").Struct("<8Q2q8i")
+
+    @classmethod
+    def _rec(cls, ptrs, longs=(), ints=()):
+        ptrs = [0 if t is None else (t if isinstance(t, int) else t.data_ptr()) for t in ptrs]
+        return cls._FIN.pack(*(ptrs + [0] * (8 - len(ptrs))), *(list(longs) + [0] * (2 - len(longs))), *(list(ints) + [0] * (8 - len(ints))))
+
+    def queue_sn_dots(self, gy, y, bias, groups, Bg, M, plane, partial):
+        self._fin_dots.append(self._rec([gy, y, bias, partial], [gy.stride(0), y.stride(0)], [groups, Bg, M, plane]))
+        self._keep.append((gy, y, bias, partial))
+        self._schedule_end()
+
+    def queue_sn_rank1(self, partial, npartial, groups, sigma, sigma_stride, u, v, wv, wv_stride, gw, gu, dsig, h, wd):
+        self._fin_rank1.append(self._rec([partial, sigma, u, v, wv, gw, gu, dsig], [wv_stride], [npartial, groups, sigma_stride, h, wd]))
+        self._keep.append((partial, sigma, u, v, wv, gw, gu, dsig))
+        self._schedule_end()
+
+    def queue_sum(self, partial, count, out):
+        self._fin_sums.append(self._rec([partial, out], [], [count]))
+        self._keep.append((partial, out))
+        self._schedule_end()
+
+    def late_grad(self, param, grad):
+        """`grad` is complete only at the end of the pass: assigned to / accumulated into param.grad by the end-of-pass callback."""
+        self._side_results.append((param, grad))
+        self._schedule_end()
 
     def defer_dv(self, v_param, u_param, w, h, wd):
         """Registers a layer for the batched dv of this backward pass; returns the slot its dsigma goes to."""
@@ -266,6 +318,22 @@ class _OnStream:
         return False
 
 
+class _Deferral:
+    """with runtime.finalisers_deferred(False): every layer finishes its parameter gradients inside its own backward node
+    (see Runtime.defer_finalisers)."""
+
+    def __init__(self, rt, on):
+        self.rt, self.on = rt, bool(on)
+
+    def __enter__(self):
+        self.prev = self.rt.defer_finalisers
+        self.rt.defer_finalisers = self.on
+
+    def __exit__(self, *exc):
+        self.rt.defer_finalisers = self.prev
+        return False
+
+
 DEFAULT_RUNTIME = Runtime()     # layers used on their own (not inside a Generator / Discriminator)
 
 
@@ -290,13 +358,18 @@ def reset_backward_state(*runtimes):
 class _GradSlot:
     """Gradient buffer shared by the backward kernels of the two consumers of a forked tensor.  claim() hands out the buffer
     and says whether it already holds the other consumer's share (then the kernel accumulates)."""
-    __slots__ = ("buf",)
+    __slots__ = ("buf", "claims")
 
     def __init__(self):
         self.buf = None
+        self.claims = 0
 
     def claim(self, like, shape=None):
         shape = tuple(like.shape if shape is None else shape)
+        self.claims += 1
+        if self.claims > 2:
+            raise RuntimeError("fork: more than two backward kernels claimed one fan-out buffer - each alias of a forked tensor "
+                               "must feed exactly one participating consumer")
         if self.buf is None:
             self.buf = like.new_empty(shape)
             return self.buf, 0
@@ -309,7 +382,11 @@ class ForkFn(torch.autograd.Function):
     gradients with one more launch and one more pass over the tensor.  Consumers that know about the fork (inplace_norm,
     residual_gate, feature_pool) write into ONE shared buffer instead - whichever backward kernel runs second accumulates
     (`accumulate` flags of the C ABI) - and both return that buffer; then there is nothing left to add here.  A consumer that
-    does not take part simply returns its own gradient and the sum is formed as usual."""
+    does not take part simply returns its own gradient and the sum is formed as usual.
+
+    Invariant (checked): an alias has ONE direct consumer.  If a participating consumer's alias also fed a second op, autograd
+    would sum the shared buffer into a fresh tensor before the other branch has accumulated into it, and the first share would
+    be counted twice - so a branch that claimed the buffer must deliver exactly that buffer."""
 
     @staticmethod
     def forward(ctx, x, slot):
@@ -319,9 +396,14 @@ class ForkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, gb):
         slot, ctx.slot = ctx.slot, None
-        slot.buf = None
+        buf, claims = slot.buf, slot.claims
+        slot.buf, slot.claims = None, 0
         if ga is None or gb is None:
             return (gb if ga is None else ga), None
+        shared = [g for g in (ga, gb) if buf is not None and g.data_ptr() == buf.data_ptr()]
+        if len(shared) != claims:
+            raise RuntimeError("fork: %d consumer(s) accumulated into the shared gradient buffer but %d branch(es) delivered it - an "
+                               "alias of a forked tensor fed more than one op" % (claims, len(shared)))
         if ga.data_ptr() == gb.data_ptr():
             return ga, None
         return ga + gb, None
@@ -404,8 +486,10 @@ class GateFn(torch.autograd.Function):
     """out = (gamma * a + 1) * x;  `a` has x's shape or is [B, C, 1, 1] (one value per plane)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, stats_groups=0, holder=None, slot=None):
+    def forward(ctx, x, a, gamma, stats_groups=0, holder=None, slot=None, rt=None):
         ctx.slot = slot
+        ctx.rt = rt or DEFAULT_RUNTIME
+        ctx.gamma_param = gamma
         x = _c(x, "gate input")
         a = _c(a, "gate attention")
         gamma = _c(gamma, "gate gamma")
@@ -433,15 +517,24 @@ class GateFn(torch.autograd.Function):
         x, a, gamma = ctx.saved_tensors
         g = _c(g)
         L = lib()
+        rt = ctx.rt
         planes = x.shape[0] * x.shape[1]
         hw = x.numel() // planes
         dx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
         da = torch.empty_like(a)
-        dgamma = torch.empty_like(gamma)
+        need_gamma = ctx.needs_input_grad[2]
+        # d(gamma) only feeds the parameter's gradient: with deferral its final sum joins the pass's batched finalisers and
+        # the result is assigned at the end of the pass; a frozen gamma (the G-step's discriminator pass) needs none at all
+        deferred = need_gamma and rt.defer_finalisers and ctx.gamma_param.is_leaf
+        dgamma = torch.empty_like(gamma) if need_gamma else None
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
-        check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), _p(dgamma), planes, hw, _p(ws),
-                                acc, _stream()), "locate_gate_bwd")
-        return dx, da, dgamma, None, None, None
+        check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), None if deferred else _p(dgamma),
+                                planes, hw, _p(ws), acc, _stream()), "locate_gate_bwd")
+        if deferred:
+            rt.queue_sum(ws, L.locate_gate_bwd_partials(planes, hw), dgamma)
+            rt.late_grad(ctx.gamma_param, dgamma.view(ctx.gamma_param.shape))
+            dgamma = None
+        return dx, da, dgamma, None, None, None, None
 
 
 def residual_gate(x, a, gamma, runtime=None, with_stats=True):
@@ -449,9 +542,9 @@ def residual_gate(x, a, gamma, runtime=None, with_stats=True):
     runtime's current stacked-call grouping) on the result, so that a norm consuming it skips its own statistics pass."""
     slot = _slot_of(x) if x.is_contiguous() else None
     if not with_stats:
-        return GateFn.apply(x, a, gamma, 0, None, slot)
+        return GateFn.apply(x, a, gamma, 0, None, slot, runtime)
     holder = []
-    out = GateFn.apply(x, a, gamma, (runtime or DEFAULT_RUNTIME).stacked, holder, slot)
+    out = GateFn.apply(x, a, gamma, (runtime or DEFAULT_RUNTIME).stacked, holder, slot, runtime)
     if holder:
         out._locate_stats = holder[0]
     return out
@@ -771,17 +864,29 @@ def _sigma_args(sigma, batch):
 def _counters(owner, adjoint):
     """Arrival counters of one layer and direction for the in-launch split-K combine (locate_conv_counter_bytes: zero at
     creation, left zero by every launch).  Per layer, direction AND stream: the same layer may run on several streams at
-    once (three-stream D-step), and launches that can overlap must not share a block."""
+    once (three-stream D-step), and launches that can overlap must not share a block.
+
+    Under hipGraph capture nothing may be allocated or zero-filled here, so a capturing stream uses the block the eager
+    warm-up iterations created FOR THAT STREAM (TrainStep's three D-step streams are the same objects eagerly and while
+    capturing: their branches of one graph keep separate blocks); a capturing stream that never ran eagerly - the capture's
+    origin stream - takes the spare block (key 0) created together with the first eager one.  One origin stream per capture,
+    so the spare block is never shared by concurrent branches."""
     cache = owner.__dict__.setdefault("_locate_counters", {})
-    key = (adjoint, torch.cuda.current_stream().cuda_stream if not torch.cuda.is_current_stream_capturing() else 0)
+    sid = torch.cuda.current_stream().cuda_stream
+    key = (adjoint, sid)
     buf = cache.get(key)
-    if buf is None or buf.device != owner.device:
-        # (the block used under hipGraph capture - key 0 - is created together with the first eager one, so that a capture,
-        # which always follows eager warm-up iterations, never allocates or zero-fills anything here)
-        for k in {key, (adjoint, 0)}:
+    if buf is not None and buf.device == owner.device:
+        return buf
+    if torch.cuda.is_current_stream_capturing():
+        buf = cache.get((adjoint, 0))
+        if buf is None or buf.device != owner.device:
+            raise RuntimeError("hipGraph capture of a contraction that never ran eagerly: run one eager iteration first (its "
+                               "arrival counters must exist before the capture)")
+        return buf
+    for k in {key, (adjoint, 0)}:
+        if k not in cache or cache[k].device != owner.device:
             cache[k] = torch.zeros(lib().locate_conv_counter_bytes(), dtype=torch.uint8, device=owner.device)
-        buf = cache[key]
-    return buf
+    return cache[key]
 
 
 def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0):
@@ -856,7 +961,9 @@ def _weight_grad_partials(spec, geom, garr):
 
 def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v):
     """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
-    (Runtime.defer_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side)."""
+    (Runtime.defer_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side).
+    With rt.defer_finalisers the rank-1 term, du and dsigma (and the stacked calls' dots) are only QUEUED here: the returned
+    buffers are complete after the pass's batched finalisers have run (Runtime._end_of_backward)."""
     L = lib()
     st = _stream()
     groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
@@ -871,10 +978,17 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
         _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision)
         dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
-        gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
         Bn, Mn = gy.shape[0], gy.shape[1]
-        check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bias), groups, Bn // groups, Mn,
-                                             gy.numel() // (Bn * Mn), _p(sigma), sigma.stride(0), _p(u), _p(v), _p(wv),
+        plane = gy.numel() // (Bn * Mn)
+        if rt.defer_finalisers:
+            npart = L.locate_fin_sn_dot_partials(Bn // groups, Mn, plane)
+            partial = torch.empty(groups * npart, dtype=torch.float64, device=x.device)
+            rt.queue_sn_dots(gy, y, bias, groups, Bn // groups, Mn, plane, partial)
+            rt.queue_sn_rank1(partial, npart, groups, sigma, sigma.stride(0), u, v, wv, wv.stride(0), gw, gu, dsig, h, wd)
+            return gw, gu
+        gws = _ws(L.locate_sn_group_workspace_bytes(), x.device)
+        check(L.locate_sn_weight_bwd_grouped(_p(gy), _bs(gy), _p(y), _bs(y), _p(bias), groups, Bn // groups, Mn, plane,
+                                             _p(sigma), sigma.stride(0), _p(u), _p(v), _p(wv),
                                              wv.stride(0), _p(gw), _p(gu), _p(dsig), h, wd, _p(gws), st),
               "locate_sn_weight_bwd_grouped")
         return gw, gu
@@ -884,6 +998,9 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
     _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision)
     dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
+    if rt.defer_finalisers:
+        rt.queue_sn_rank1(partial, npart, 0, sigma, 0, u, v, wv, 0, gw, gu, dsig, h, wd)
+        return gw, gu
     check(L.locate_sn_weight_bwd(_p(partial), npart, _p(u), _p(v), _p(sigma), _p(wv), _p(gw), _p(gu), _p(dsig), h, wd, st),
           "locate_sn_weight_bwd")
     return gw, gu
@@ -949,21 +1066,23 @@ class SNConvFn(torch.autograd.Function):
         if need_w or need_u or need_v:
             rt = ctx.rt
             side = rt.weight_grad_stream
+            late = side is not None or rt.defer_finalisers     # the gradients bypass autograd: assigned at the end of the pass
             if side is None:
-                gw, gu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
-                if not need_w:
-                    gw = None
+                sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
             else:
                 side.wait_stream(torch.cuda.current_stream())        # gy (and x) are complete on the pass's stream
                 with torch.cuda.stream(side):
                     sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
                 rt._side = side
+            if late:
                 rt._keep.append((x, gy, y, bsaved, w, sigma, wv))
                 if need_w:
-                    rt._side_results.append((ctx.owner, sgw.view(ctx.owner.shape)))
+                    rt.late_grad(ctx.owner, sgw.view(ctx.owner.shape))
                 if need_u:
-                    rt._side_results.append((ctx.u, sgu))
+                    rt.late_grad(ctx.u, sgu)
                 rt._schedule_end()
+            else:
+                gw, gu = (sgw if need_w else None), sgu
         if ctx.has_bias and need_b:
             gb = _bias_grad(gy)
         # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass

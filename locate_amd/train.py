@@ -77,14 +77,23 @@ class TrainStep:
         self._streams = None
 
     def _backward(self, outputs, grads):
+        import contextlib
         from . import ops
         runtimes = [getattr(net, "runtime", ops.DEFAULT_RUNTIME) for net in (self.gen, self.dis)]
         ops.reset_backward_state(*runtimes)
-        if not self.overlap_wgrad:
-            return torch.autograd.backward(outputs, grads)
-        if self._wgrad_side is None:
-            self._wgrad_side = torch.cuda.Stream()
-        with runtimes[0].weight_grads_on(self._wgrad_side), runtimes[1].weight_grads_on(self._wgrad_side):
+        # A data-parallel reducer driven by post-accumulate hooks (eager mode) needs every gradient complete when autograd
+        # hands it over, so the layers then finish their own gradients; otherwise the small per-layer finalisers are batched
+        # at the end of the pass (ops.Runtime.defer_finalisers).  Under hipGraph capture the reducers are detached
+        # (graph.py) and the exchange is launched between the graphs: deferral stays on there.
+        defer = self.reducer_g is None and self.reducer_d is None
+        with contextlib.ExitStack() as stack:
+            for rt in runtimes:
+                stack.enter_context(rt.finalisers_deferred(defer))
+            if self.overlap_wgrad:
+                if self._wgrad_side is None:
+                    self._wgrad_side = torch.cuda.Stream()
+                for rt in runtimes:
+                    stack.enter_context(rt.weight_grads_on(self._wgrad_side))
             return torch.autograd.backward(outputs, grads)
 
     # ---- the four phases of one iteration (kept separate so that each can be its own hipGraph) --------------

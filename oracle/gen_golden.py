@@ -477,7 +477,54 @@ def _gen_step_record(name, S, B, ff, **consts):
     _save(name, d)
 
 
-GROUPS = {"ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
+def gen_f64():
+    """The reference's own fp32 rounding noise on the ill-conditioned scalars of a step, per configuration: the same seeded
+    build and the same inputs run twice through the REFERENCE, once as shipped (fp32) and once with both networks converted
+    to float64 (`module.double()`, `G.noise.double()`, double inputs).  Stored: every gate's d(gamma) (merge.py:33-38, a sum
+    with heavy cancellation) from both runs, the losses and the consistency penalty (grad_penalty.py:1-2) from both runs,
+    and the float64 gradient norms of every tensor.  The GPU tests then hold the kernels to a multiple of
+    |ref32 - ref64| - the deviation the reference shows against itself - instead of to a bound derived from the build."""
+    import warnings
+    import torch
+    from ref_loader import load_reference
+    which = os.environ["LOCATE_GOLDEN_F64"]
+    name, S, B, ff = F64_RECORDS[which]
+    ns = load_reference(S, ff)
+    warnings.simplefilter("ignore")
+    runs = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        G, GO, D, DO = _build_models(ns, 999)
+        latent = torch.randn(B, S)
+        real = torch.randn(B, 3, S, S).clamp(-1, 1)
+        aug = torch.randn(B, 3, S, S).clamp(-1, 1)
+        if dt is torch.float64:
+            G, D = G.double(), D.double()
+            G.noise = G.noise.double()
+            latent, real, aug = latent.double(), real.double(), aug.double()
+        runs[tag] = (_train_step(ns, G, GO, D, DO, latent, real, aug), latent)
+    d = {"after_build_rng_check": _np(runs["f32"][1][0, :4])}
+    for tag, (rec, _) in runs.items():
+        for k in ("d_error", "penalty", "g_error"):
+            d["%s/%s" % (tag, k)] = np.float64(rec[k].double())
+        for net, gr in (("D", rec["d_grads"]), ("G", rec["g_grads"])):
+            gam = [k for k in gr if k.endswith("gamma")]
+            d["%s/%s/gamma_keys" % (tag, net)] = np.array(gam)
+            d["%s/%s/gamma_grads" % (tag, net)] = np.array([float(gr[k].double().sum()) for k in gam])
+            d["%s/%s/grad_keys" % (tag, net)] = np.array(list(gr.keys()))
+            d["%s/%s/grad_norms" % (tag, net)] = np.array([float(v.double().norm()) for v in gr.values()])
+    _save(name + "_f64", d)
+
+
+F64_RECORDS = {
+    "config1": ("g11_config1", 32, 8, 8),
+    "config2": ("g14_config2_64", 64, 64, 8),
+    "config3": ("g12_config3_128", 128, 2, 8),
+    "size256": ("g13_256_narrow", 256, 2, 1),
+    "size256_full": ("g20_256_full", 256, 2, 8),
+}
+
+
+GROUPS = {"f64": gen_f64, "ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
           "config2": gen_config2, "size256": gen_size256, "size256_full": gen_size256_full, "variants": gen_variants}
 
 
@@ -489,6 +536,7 @@ def main(argv):
     runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {}), ("size256_full", {})]
     runs += [("init", {"LOCATE_GOLDEN_INIT_CFG": c}) for c in ("tiny32", "full32", "full64")]
     runs += [("variants", {"LOCATE_GOLDEN_VARIANT": v}) for v in VARIANTS]
+    runs += [("f64", {"LOCATE_GOLDEN_F64": v}) for v in F64_RECORDS]
     for name, extra in runs:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), name], env=dict(env, **extra),
                               cwd="/tmp")
