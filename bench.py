@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--dp-wgrad-overlap", action="store_true",
                     help="also with --gpus N > 1 (correct - tests/test_gpu_dp.py - but unmeasured on RCCL: the only rehearsal "
                          "possible here, two gloo ranks time-slicing ONE GPU, runs 17x slower with it, 3.3 s vs 0.19 s per step)")
+    ap.add_argument("--f16-min-gflop", type=float, default=None,
+                    help="work threshold (GFLOP per launch) above which a fp32-faithful contraction takes its fp16-piece form "
+                         "(default: locate_amd.ops.F16_MIN_FLOPS); a huge value turns the form off")
     ap.add_argument("--no-overlap", action="store_true",
                     help="replay the G-step's generator pass in line instead of on a second stream beside the D-step")
     return ap.parse_args()
@@ -181,15 +184,15 @@ def hbm_bound_block(batch, dev, reps=10):
         Bn, C, H, W = shape
         hw, planes, n = H * W, Bn * C, Bn * C * H * W
         x, g, y, gx, a = (torch.randn(shape, device=dev) for _ in range(5))
-        add("RootTanh fwd", shape, 2 * n_act, 8 * n, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, st)))
-        add("RootTanh bwd", shape, n_act, 12 * n, lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, st)))
+        add("RootTanh fwd", shape, 2 * n_act, 8 * n, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, None, st)))
+        add("RootTanh bwd", shape, n_act, 12 * n, lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, None, st)))
         if n_norm:
             w_, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
             dw, db, stats = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(2, device=dev)
             ws_f = torch.empty(max(L.locate_norm_stats_workspace_bytes(), 16), dtype=torch.uint8, device=dev)
             ws_b = torch.empty(max(L.locate_norm_bwd_workspace_bytes(Bn, C), 16), dtype=torch.uint8, device=dev)
             add("InPlaceNorm fwd (stats + apply)", shape, 2 * n_norm, 12 * n,
-                lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), None, st)))
+                lambda: check(L.locate_norm_fwd(P(x), P(w_), 0, P(b_), P(y), 0, P(stats), Bn, C, hw, 1, P(ws_f), None, None, st)))
             add("InPlaceNorm bwd", shape, n_norm, 20 * n,
                 lambda: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w_), 0, P(b_), 0, P(gx), P(dw), P(db), Bn, C, hw, 1, P(ws_b), 0, st)))
         if n_gate:
@@ -277,6 +280,9 @@ def main():
     from locate_amd.graph import GraphedTrainStep
     require_gpu()
 
+    if args.f16_min_gflop is not None:
+        from locate_amd import ops as _ops
+        _ops.F16_MIN_FLOPS = args.f16_min_gflop * 1e9
     cfg = NetConfig(image_size=args.image_size)
     torch.manual_seed(cfg.seed)
     G, GO = get_model(Generator(cfg), cfg.glr, dev)

@@ -29,8 +29,15 @@ int locate_abi_version(void);
 int locate_device_info(char* arch_name, int name_len, int* cu_count, int* wave_size);
 
 /* ---- RootTanh: y = (x^2+1)^(1/4) tanh x and its hand-written derivative (libs/activation.py:7-36) ---- */
-int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream);
-int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* stream);   /* accumulate: gx += */
+int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* absmax /* nullable, see locate_roottanh_bwd */, void* stream);
+/* accumulate: gx +=.  absmax (nullable): locate_absmax_words() (= 1024: 32 words in use, one per 128-byte line) device words,
+ * ZERO before the call; the kernel folds the largest |gx| into them (atomic max on the bit pattern - order-independent - spread
+ * over cache lines so that a few thousand blocks do not queue on one; the tensor's maximum is the maximum of the words) for a
+ * contraction that consumes gx in its fp16-piece form (precision 2 below) */
+int locate_absmax_words(void);
+int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* absmax, void* stream);
+/* the same word for any tensor (tests, tools, weights packed outside an optimizer step) */
+int locate_absmax(const float* x, int64_t n, void* absmax, void* stream);
 /* generator output tanh (libs/models.py:66); backward takes the forward OUTPUT y */
 /* style chain link (libs/block.py:119-125): out[r, :z] = latent[r, :], out[r, z:] = RootTanh(pre[r, :]) in one launch, and
  * its backward on the gradient's column slice in place (row stride in elements) */
@@ -52,7 +59,7 @@ int locate_norm_stats(const float* x, int64_t n, float* stats, void* workspace, 
  * the same group count); the statistics pass over x is then skipped */
 int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out, int with_act,
                     float* stats_out, int B, int C, int hw, int groups, void* workspace, const double* pre_partial,
-                    void* stream);
+                    void* absmax /* nullable: largest |out|, see locate_roottanh_bwd */, void* stream);
 size_t locate_norm_bwd_workspace_bytes(int B, int C);
 /* full backward incl. the path through std (libs/inplace_norm.py:17-27 + ATen std backward); with_act = 1: g is the
  * gradient w.r.t. RootTanh(out) and RootTanh' (libs/activation.py:22-36) is applied from the recomputed out;
@@ -139,7 +146,8 @@ int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* 
 size_t locate_conv_pack_job_bytes(void);
 int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
                          int* blocks_out);
-int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream);
+int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16 /* some job has the format bit */,
+                            void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
 /* arrival counters for split-K launches that combine their partial tiles INSIDE the launch (the tile's last-arriving block
  * sums them in a fixed order: bit-reproducible): locate_conv_counter_bytes() bytes of device memory, zero before their first
@@ -153,12 +161,19 @@ size_t locate_conv_counter_bytes(void);
  * configs[1] names; tolerance against the fp32 path stated in tests/test_gpu_bf16.py. */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                     int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
-                    void* counters, int precision, void* stream);
+                    void* counters, int precision, const void* x_absmax, void* stream);
+/* precision: 0 = fp32-faithful with three bf16 pieces per operand (six bf16 MFMAs per 32x32x16 slice); 1 = operands rounded
+ * to bf16 (one MFMA); 2 = fp32-faithful with TWO fp16 pieces per operand (three fp16 MFMAs): both operands are scaled by a
+ * power of two into fp16's range - the weights when the panel is packed (panel format bit: `adjoint | 2` in
+ * locate_conv_panel_bytes / locate_conv_pack_panel / locate_conv_pack_job), the gathered tensor inside the kernel from
+ * *x_absmax, the bit pattern of its largest magnitude (locate_absmax, or the absmax outputs of the producing kernels) - and
+ * the exact inverse factors are applied to the accumulators.  Same fp32-level accuracy as precision 0 (tools/bench_conv.py
+ * --check), half the matrix instructions. */
 /* data adjoint of R (= ConvTranspose2d forward with weight [C_in = M, C_out = C, KH, KW]); panel: adjoint = 1 */
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                       int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
-                      void* counters, int precision, void* stream);
+                      void* counters, int precision, const void* gy_absmax, void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.
@@ -168,7 +183,8 @@ size_t locate_conv_wgrad_workspace_bytes(const int* geom);
 int locate_conv_wgrad_partials(const int* geom);
 int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
-                      double* inner_partial, void* workspace, int precision, void* stream);
+                      double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
+                      void* stream);
 
 /* ---- grouped convolutions of the SEPARABLE switch (libs/config.py:53; replaces the torch.nn.Conv2d /
  *      ConvTranspose2d(groups = ...) forward + autograd backward under libs/conv.py:14-18 and libs/attention.py:15-21).

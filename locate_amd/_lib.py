@@ -27,16 +27,18 @@ PROTOTYPES = {
     "locate_last_error": (ctypes.c_char_p, []),
     "locate_abi_version": (c_i, []),
     "locate_device_info": (c_i, [ctypes.c_char_p, c_i, c_ip, c_ip]),
-    "locate_roottanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
-    "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
+    "locate_roottanh_fwd": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
+    "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "locate_act_cat_rows_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "locate_act_rows_bwd": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, c_p]),
+    "locate_absmax_words": (c_i, []),
+    "locate_absmax": (c_i, [c_p, c_i64, c_p, c_p]),
     "locate_tanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "locate_tanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "locate_norm_stats_workspace_bytes": (c_sz, []),
     "locate_norm_stats": (c_i, [c_p, c_i64, c_p, c_p, c_p]),
     "locate_norm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
-    "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "locate_channel_sum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "locate_channel_sum": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_p, c_p]),
@@ -66,15 +68,15 @@ PROTOTYPES = {
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_pack_job_bytes": (c_sz, []),
     "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip]),
-    "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_p]),
+    "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_counter_bytes": (c_sz, []),
-    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p]),
+    "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p]),
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p]),
+    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p]),
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
-    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
     "locate_dwconv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "locate_dwconv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "locate_dwconv_wgrad_workspace_bytes": (c_sz, [c_ip]),
@@ -104,7 +106,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 4
+EXPECTED_ABI = 5
 
 
 _lib = None

@@ -59,6 +59,42 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// A tensor's largest magnitude for the contractions' fp16-piece scaling (conv.hip): every producing block folds its maximum into
+// a small VECTOR of device words with an atomic max on the bit pattern (non-negative floats order like unsigned integers, and a
+// maximum does not depend on the order of arrival: deterministic); the consumer takes the maximum of the words.  One word would
+// do, but atomics on one CACHE LINE serialise at ~90 per microsecond - a 2048-block element-wise launch whose blocks all
+// finish together paid 12-20 us for it, more than the kernel itself - so block b goes to word AMAX_STRIDE * (b % AMAX_LINES):
+// 32 words on 32 different 128-byte lines (<= 64 arrivals each), AMAX_WORDS = 1024 words (4 KiB) per tensor, of which only those
+// 32 are ever touched.  The words must be zero before the producer starts.  `scratch`: >= 16 floats.
+#define AMAX_LINES 32
+#define AMAX_STRIDE 32
+#define AMAX_WORDS (AMAX_LINES * AMAX_STRIDE)
+__device__ __forceinline__ void absmax_publish(float m, float* scratch, unsigned* slot) {
+    m = wave_max(m);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = scratch[0];
+        for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+        unsigned* word = slot + AMAX_STRIDE * ((blockIdx.x + blockIdx.y * 7u) & (AMAX_LINES - 1));
+        const unsigned bits = __float_as_uint(t);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // result unused: no return trip
+    }
+}
+// the consumer's side: maximum of the AMAX_LINES words (wave-uniform)
+__device__ __forceinline__ unsigned absmax_read(const unsigned* slot) {
+    unsigned v = slot[AMAX_STRIDE * (threadIdx.x & (AMAX_LINES - 1))];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
+        v = w > v ? w : v;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // Block-wide sum for blockDim.x <= 1024 (a multiple of 64). `scratch` holds >= 16 values.
 // Every thread returns the total.
 template <typename T>

@@ -77,11 +77,30 @@ struct PackArgs {
     int K, rows, ld;
     int gHW, gW, dy0, dys, dx0, dxs;   // geometry of the gathered tensor and of the tap grid
     int dmin;                          // min over the taps of dy*gW + dx (<= 0)
+    int fmt;                           // split section: 0 = three bf16 planes, 1 = header + two fp16 planes
 };
 
-static inline size_t panel_floats(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4 + (size_t)rows * ld / 2 * 3; }
+// fmt 0: the split section holds the three bf16 planes; fmt 1 ("fp16 pieces", see conv_igemm_bx6_kernel NP = 2): a 4-dword
+// header {absmax bits of this phase's weights, 0, 0, 0} followed by TWO fp16 planes of the weights times 2^k(absmax)
+#define PANEL_HDR 4
+static inline size_t panel_floats(int rows, int ld, int fmt) {
+    return (size_t)rows * ld + rows + rows / 4 + (fmt ? PANEL_HDR + (size_t)rows * ld / 2 * 2 : (size_t)rows * ld / 2 * 3);
+}
 static inline size_t panel_split_offset(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }   // floats
 __device__ __forceinline__ size_t panel_split_offset_dev(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
+
+// Scale exponent of a tensor whose largest magnitude has the fp32 bit pattern `bits`: k with absmax * 2^k in [2^14, 2^15)
+// - one binade below fp16's largest finite value, so that the two fp16 pieces of every element (11 + 11 significant bits)
+// stay normal numbers down to elements 2^-17 of the largest (below that the low piece goes subnormal: absolute error
+// <= 2^-25 on the scaled tensor, i.e. 2^-39 of its largest element).  Zero / denormal tensors: k = 0.  Clamped so that
+// 2^k and 2^-k are normal fp32 numbers.
+__host__ __device__ __forceinline__ int f16_scale_exp(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu) - 127;
+    if (e == -127) return 0;
+    const int k = 14 - e;
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }      // -126 <= k <= 127
 
 struct PackBatch {
     PackArgs ph[4];
@@ -102,15 +121,37 @@ __device__ __forceinline__ void pack_tables(const PackArgs& a, int k) {
     ktap[k] = (unsigned char)tap;
 }
 
+// fp16-piece panels: a packing block folds the largest magnitude of the weights it handled into the header word of its
+// phase(s) (atomic max on the bit pattern, skipped when the word already holds as much: after the first few blocks almost
+// every one).  A block of the adjoint packer handles all sub-pixel phases of its weights and reports to each of them the
+// maximum over ALL its taps - an upper bound of the phase's own, which is all the scale exponent needs.
+__device__ __forceinline__ void pack_publish_absmax(float m, const PackArgs* phases, int nphase, float* red) {
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        for (int i = 0; i < nphase; ++i) {
+            const PackArgs& a = phases[i];
+            if (!a.fmt) continue;
+            unsigned* word = reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld));
+            if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 #define PACK_MAX_TAPS 32
 #define PACK_SMEM (256 * (PACK_MAX_TAPS + 1))      // floats; also holds the 64 x 65 transpose tile
 
 // generic element-wise form (any tap count): virtual grid (nbx, nphase)
-__device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx, int by, int nbx) {
+__device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx, int by, int nbx, float* smem) {
     const PackArgs& a = batch.ph[by];
     const int64_t total = (int64_t)a.rows * a.ld;
     const int64_t stride = (int64_t)nbx * 256;
     const int T = a.TH * a.TW;
+    float am = 0.0f;
     for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
         const int k = (int)(i / a.ld), col = (int)(i - (int64_t)k * a.ld);
         float v = 0.0f;
@@ -131,8 +172,10 @@ __device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx
             }
         }
         a.out[i] = v;
+        am = fmaxf(am, fabsf(v));
     }
     for (int64_t k = (int64_t)bx * 256 + threadIdx.x; k < a.rows; k += stride) pack_tables(a, (int)k);
+    if (a.fmt) pack_publish_absmax(am, &a, 1, smem);
 }
 
 // mode 0 (R forward): the panel is the transpose of W viewed as [M][K]: 64 x 64 tiles through LDS, both the read
@@ -141,9 +184,12 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
     float (*tile)[65] = reinterpret_cast<float (*)[65]>(smem);
     const int k0 = bx * 64, m0 = by * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float am = 0.0f;
     for (int j = ty; j < 64; j += 4) {
         const int m = m0 + j, k = k0 + tx;
-        tile[j][tx] = (m < a.M && k < a.K) ? a.w[(int64_t)m * a.K + k] : 0.0f;
+        const float v = (m < a.M && k < a.K) ? a.w[(int64_t)m * a.K + k] : 0.0f;
+        tile[j][tx] = v;
+        am = fmaxf(am, fabsf(v));
     }
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
@@ -151,6 +197,7 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
         if (k < a.rows && m < a.ld) a.out[(int64_t)k * a.ld + m] = tile[tx][j];
     }
     if (by == 0 && threadIdx.x < 64 && k0 + (int)threadIdx.x < a.rows) pack_tables(a, k0 + threadIdx.x);
+    if (a.fmt) pack_publish_absmax(am, &a, 1, smem + 64 * 65);       // PACK_SMEM floats: room behind the tile
 }
 
 // mode 1 (data adjoint, all sub-pixel phases at once): for one m, W[m] is a [C][KH*KW] matrix; a block stages 256
@@ -161,6 +208,7 @@ __device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int np
     const int KK = a0.KH * a0.KW, S = KK | 1;
     const int m = by, c0 = bx * 256;
     const int col = c0 + threadIdx.x;
+    float am = 0.0f;
     if (m < a0.M) {
         const int cn = min(256, a0.C - c0);
         if (cn > 0) {
@@ -168,7 +216,9 @@ __device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int np
             const int total = cn * KK;
             for (int idx = threadIdx.x; idx < total; idx += 256) {
                 const int cl = idx / KK, t = idx - cl * KK;
-                lds[cl * S + t] = src[idx];
+                const float v = src[idx];
+                lds[cl * S + t] = v;
+                am = fmaxf(am, fabsf(v));
             }
         }
         __syncthreads();
@@ -182,6 +232,7 @@ __device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int np
                 a.out[((int64_t)m * T + r) * a.ld + col] = (int)threadIdx.x < cn ? lds[threadIdx.x * S + t] : 0.0f;
             }
         }
+        if (a0.fmt) pack_publish_absmax(am, batch.ph, nphase, lds + 256 * (PACK_MAX_TAPS + 1) - 8);
         return;
     }
     for (int ph = 0; ph < nphase; ++ph) {
@@ -235,12 +286,52 @@ __device__ __forceinline__ void split3_trunc_x8(const float (&v)[8], uint4& h, u
     split3_trunc_pair(v[6], v[7], h.w, m.w, l.w);
 }
 
-// second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// x * 2^k = h + l up to 2^-22 |x| with h = fp16(x 2^k), l = fp16(x 2^k - h), both rounded to nearest even
+__device__ __forceinline__ void split2_f16x8(const float (&v)[8], float sc, uint4& h, uint4& l) {
+    f16x8 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * sc;
+        hh[j] = (_Float16)x;
+        ll[j] = (_Float16)(x - (float)hh[j]);
+    }
+    h = *reinterpret_cast<uint4*>(&hh);
+    l = *reinterpret_cast<uint4*>(&ll);
+}
+
+// the same for one pair of values, packed (v0 in the low halves)
+__device__ __forceinline__ void split2_f16_pair(float v0, float v1, unsigned& h, unsigned& l) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 hh, ll;
+    hh[0] = (_Float16)v0; hh[1] = (_Float16)v1;
+    ll[0] = (_Float16)(v0 - (float)hh[0]); ll[1] = (_Float16)(v1 - (float)hh[1]);
+    h = *reinterpret_cast<unsigned*>(&hh);
+    l = *reinterpret_cast<unsigned*>(&ll);
+}
+
+// second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k), or
+// its two scaled fp16 planes
 __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int nbx) {
     const float* w = a.out;
-    uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld));
+    uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
     const int64_t total = (int64_t)(a.rows / 8) * a.ld;
     const int64_t stride = (int64_t)nbx * 256;
+    if (a.fmt) {
+        const float sc = pow2f(f16_scale_exp(*reinterpret_cast<const unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld))));
+        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
+            const int kb = (int)(i / a.ld), col = (int)(i - (int64_t)kb * a.ld);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w[(int64_t)(kb * 8 + j) * a.ld + col];
+            uint4 h, l;
+            split2_f16x8(v, sc, h, l);
+            w3[i] = h;
+            w3[total + i] = l;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
         const int kb = (int)(i / a.ld), col = (int)(i - (int64_t)kb * a.ld);
         float v[8];
@@ -285,7 +376,7 @@ __device__ __forceinline__ void pack_job_body(const PackJob& j, int local, float
     const int bx = local % j.gx, by = local / j.gx;
     if (j.kind == 0) pack_transpose_body(j.batch.ph[0], bx, by, smem);
     else if (j.kind == 1) pack_adjoint_body(j.batch, j.nphase, bx, by, smem);
-    else pack_generic_body(j.batch, bx, by, j.gx);
+    else pack_generic_body(j.batch, bx, by, j.gx, smem);
 }
 
 __global__ void __launch_bounds__(256) pack_job_kernel(const PackJob job) {
@@ -298,6 +389,19 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const PackJob job) {
     if ((int)blockIdx.y < job.nphase) pack_split_body(job.batch.ph[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
+// fp16-piece panels only: zero the absmax words (one thread per (job, phase)), then take the maxima
+__device__ __forceinline__ void pack_clear_one(const PackJob& j, int ph) {
+    if (ph < j.nphase && j.batch.ph[ph].fmt) {
+        const PackArgs& a = j.batch.ph[ph];
+        unsigned* hdr = reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld));
+        hdr[0] = 0u; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u;
+    }
+}
+__global__ void __launch_bounds__(64) pack_clear_kernel(const PackJob job) { if (threadIdx.x < 4) pack_clear_one(job, threadIdx.x); }
+__global__ void __launch_bounds__(64) pack_clear_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < 4 * n_jobs) pack_clear_one(jobs[i >> 2], i & 3);
+}
 // blockIdx.y = job, blockIdx.z = phase
 __global__ void __launch_bounds__(256) pack_split_jobs_kernel(const PackJob* __restrict__ jobs) {
     const PackJob& j = jobs[blockIdx.y];
@@ -326,7 +430,8 @@ struct IgPhase {
     const float* wp;             // packed weights [rows][ld]
     const int* koff;             // [rows]
     const unsigned char* ktap;   // [rows]
-    const uint4* w3;             // [3][rows / 8][ld] chunks of 8 bf16 (see the panel layout)
+    const uint4* w3;             // [3][rows / 8][ld] chunks of 8 bf16, or [2][rows / 8][ld] chunks of 8 fp16 (see the panel layout)
+    const unsigned* a_absmax;    // fp16-piece panels: bit pattern of the largest weight magnitude of this phase
     long long w3_plane;          // chunks per plane
     int K, Kpad, ld, T;
     int dmin;                    // the buffer descriptor of the gather starts dmin (<= 0) elements before the tensor
@@ -350,7 +455,9 @@ struct IgParams {
     int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab`
     float* slab;         //   combine == 0: dense [ksplit][B, M, OH, OW], summed by igemm_slab_reduce_kernel
     long long slab_stride;
-    int precision;       // 0: fp32-faithful (three bf16 pieces per operand, six MFMAs per slice); 1: bf16 operands (one piece)
+    int precision;       // 0: fp32-faithful (three bf16 pieces per operand, six MFMAs per slice); 1: bf16 operands (one piece);
+                         // 2: fp32-faithful with two scaled fp16 pieces per operand, three MFMAs per slice (panel format 1)
+    const unsigned* b_absmax;   // precision 2: largest magnitude of the gathered tensor as AMAX_WORDS words of bit patterns (common.h)
     int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
     unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
     IgPhase ph[4];
@@ -713,6 +820,16 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
     const GatherCol gc = gather_setup(p, ph, n0 + ncol, N);
     float col_scale[TN];
     igemm_col_scales<WGM, WGN, TM, TN>(p, ph, col_scale, N, n0, wn, lane);
+    // fp16 pieces: both operands are scaled by powers of two into fp16's range (the weights when their planes were packed,
+    // the gathered tensor below); the exact inverse factors go back in after the K loop
+    float b_scale = 1.0f, a_unscale = 1.0f, b_unscale = 1.0f;
+    if constexpr (NP == 2) {
+        const int kb_ = f16_scale_exp(absmax_read(p.b_absmax));
+        const int ka_ = f16_scale_exp(__builtin_amdgcn_readfirstlane(*ph.a_absmax));
+        b_scale = pow2f(kb_);
+        a_unscale = pow2f(-ka_);
+        b_unscale = pow2f(-kb_);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -752,17 +869,13 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
     unsigned long long taps = *reinterpret_cast<const unsigned long long*>(ph.ktap + __builtin_amdgcn_readfirstlane(kidx));   // s_load_dwordx2
     auto issue_loads = [&]() {
         areg0 = ap[0];
-        if constexpr (NP == 3) {
-            areg1 = ap[a_plane];
-            areg2 = ap[2 * a_plane];
-        }
+        if constexpr (NP >= 2) areg1 = ap[a_plane];
+        if constexpr (NP == 3) areg2 = ap[2 * a_plane];
         ap += a_step;
         if constexpr (A2) {
             areg3 = bp[0];
-            if constexpr (NP == 3) {
-                areg4 = bp[a_plane];
-                areg5 = bp[2 * a_plane];
-            }
+            if constexpr (NP >= 2) areg4 = bp[a_plane];
+            if constexpr (NP == 3) areg5 = bp[2 * a_plane];
             bp += a_step;
         }
 #pragma unroll
@@ -775,21 +888,25 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
     auto store_tiles = [&](int buf) {
         if (a_thread) {
             As[buf][0][a_kb][a_m] = areg0;
-            if constexpr (NP == 3) {
-                As[buf][NP - 2][a_kb][a_m] = areg1;
-                As[buf][NP - 1][a_kb][a_m] = areg2;
-            }
+            if constexpr (NP >= 2) As[buf][NP >= 2 ? 1 : 0][a_kb][a_m] = areg1;
+            if constexpr (NP == 3) As[buf][NP - 1][a_kb][a_m] = areg2;
         }
         if constexpr (A2) {
             if (b_thread) {
                 As[buf][0][b_kb][b_m] = areg3;
-                if constexpr (NP == 3) {
-                    As[buf][NP - 2][b_kb][b_m] = areg4;
-                    As[buf][NP - 1][b_kb][b_m] = areg5;
-                }
+                if constexpr (NP >= 2) As[buf][NP >= 2 ? 1 : 0][b_kb][b_m] = areg4;
+                if constexpr (NP == 3) As[buf][NP - 1][b_kb][b_m] = areg5;
             }
         }
-        if constexpr (NP == 3) {
+        if constexpr (NP == 2) {
+            uint4 h, l;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = breg[j];
+            split2_f16x8(v, b_scale, h, l);
+            Bs[buf][0][kgrp][ncol] = h;
+            Bs[buf][NP - 1][kgrp][ncol] = l;
+        } else if constexpr (NP == 3) {
             uint4 h, m, l;
             float v[8];
 #pragma unroll
@@ -817,20 +934,21 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
     }
     __syncthreads();
     const int lrow = lane >> 5, lcol = lane & 31;
-    constexpr int PROD = NP == 3 ? 6 : 1;
+    constexpr int PROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
     constexpr int NMF = TM * TN * PROD, HALF = KS == 1 ? NMF / 2 : NMF;
+    using frag_t = typename std::conditional<NP == 2, f16x8, bf16x8>::type;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        bf16x8 a[TM][NP], b[TN][NP];
+        frag_t a[TM][NP], b[TN][NP];
         auto fragments = [&](int ksub) {          // the 16-deep slice `ksub` of the stage
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][2 * ksub + lrow][(wm * TM + i) * 32 + lcol]);
+                for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&As[buf][q][2 * ksub + lrow][(wm * TM + i) * 32 + lcol]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][2 * ksub + lrow][(wn * TN + j) * 32 + lcol]);
+                for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Bs[buf][q][2 * ksub + lrow][(wn * TN + j) * 32 + lcol]);
         };
         fragments(0);
         auto mfmas = [&](int lo, int hi) {
@@ -839,7 +957,11 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int base = (i * TN + j) * PROD;
-                    if constexpr (NP == 3) {
+                    if constexpr (NP == 2) {          // smallest terms first: l h, h l, h h (l l, 2^-22 of the product, is dropped)
+                        if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                        if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                        if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    } else if constexpr (NP == 3) {
                         if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);   // l h
                         if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);   // h l
                         if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
@@ -865,7 +987,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
         }
         // one vector-memory instruction (and its address arithmetic) in the shadow of every MFMA: the memory pipe takes
         // ~100 cycles per wave instruction when twelve waves queue on it, the matrix pipe 32 per MFMA
-        if constexpr (NP == 3) {
+        if constexpr (NP >= 2) {
 #pragma unroll
             for (int k = 0; k < (KS == 1 ? NMF - HALF : NMF); ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -874,6 +996,15 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
             }
         }
         __syncthreads();
+    }
+    if constexpr (NP == 2) {       // undo the two power-of-two scales, one after the other (each exact; their product may not be
+                                   // a normal fp32 number): whatever leaves this block - output or split-K partial - is unscaled
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * a_unscale) * b_unscale;
     }
     // the operand tiles are dead after the loop's last barrier: each wave takes a 32 x 33 float patch of them
     float* const stage = reinterpret_cast<float*>(smem) + wid * (32 * 33);
@@ -1293,10 +1424,14 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     // launches of at most ~one block per CU: the eight-wave form (see the kernel)
     const bool w8 = !path_disabled("w8") && !path_disabled("bx6") && (bm == 128 || bm == 64) &&
                     (long long)grid.x * grid.y * grid.z <= knob_int("LOCATE_W8_MAX", 320);
+    if (p.precision == 2) LOCATE_REQUIRE(!path_disabled("bx6"), "%s: fp16 pieces need the bf16/fp16 MFMA kernels", who);
     if (w8) {
         if (p.precision == 1) {
             if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 1, 8><<<grid, 512, 0, st>>>(p);
             else conv_igemm_bx6_kernel<2, 4, 1, 1, 1, 8><<<grid, 512, 0, st>>>(p);
+        } else if (p.precision == 2) {
+            if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 2, 8><<<grid, 512, 0, st>>>(p);
+            else conv_igemm_bx6_kernel<2, 4, 1, 1, 2, 8><<<grid, 512, 0, st>>>(p);
         } else {
             if (bm == 128) conv_igemm_bx6_kernel<2, 4, 2, 1, 3, 8><<<grid, 512, 0, st>>>(p);
             else conv_igemm_bx6_kernel<2, 4, 1, 1, 3, 8><<<grid, 512, 0, st>>>(p);
@@ -1307,6 +1442,12 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
         else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
         else conv_igemm_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
+    } else if (p.precision == 2) {
+        if (bm == 192) conv_igemm_bx6_kernel<2, 2, 3, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_igemm_bx6_kernel<1, 4, 3, 1, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_igemm_bx6_kernel<1, 4, 2, 1, 2><<<grid, 256, 0, st>>>(p);
+        else conv_igemm_bx6_kernel<1, 4, 1, 1, 2><<<grid, 256, 0, st>>>(p);
     } else if (!path_disabled("bx6")) {
         if (bm == 192) conv_igemm_bx6_kernel<2, 2, 3, 2, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 128) conv_igemm_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
@@ -1333,6 +1474,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
 // all phases of one panel in a single launch
 static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const char* who) {
     const PackJob j = make_pack_job(b, nphase);
+    if (b.ph[0].fmt) pack_clear_kernel<<<1, 64, 0, st>>>(j);      // the absmax words the packing blocks fold their maxima into
     pack_job_kernel<<<j.gx * j.gy, 256, 0, st>>>(j);
     LOCATE_LAUNCH_CHECK(who);
     int64_t big = 1;
@@ -1413,7 +1555,8 @@ static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
     ph.wp = panel_base;
     ph.koff = reinterpret_cast<const int*>(panel_base + (size_t)pa.rows * pa.ld);
     ph.ktap = reinterpret_cast<const unsigned char*>(ph.koff + pa.rows);
-    ph.w3 = reinterpret_cast<const uint4*>(panel_base + panel_split_offset(pa.rows, pa.ld));
+    ph.w3 = reinterpret_cast<const uint4*>(panel_base + panel_split_offset(pa.rows, pa.ld) + (pa.fmt ? PANEL_HDR : 0));
+    ph.a_absmax = pa.fmt ? reinterpret_cast<const unsigned*>(panel_base + panel_split_offset(pa.rows, pa.ld)) : nullptr;
     ph.w3_plane = (long long)(pa.rows / 8) * pa.ld;
     ph.dmin = pa.dmin;
     ph.K = pa.K; ph.Kpad = pa.rows - IG_TAIL; ph.ld = pa.ld;
@@ -1424,8 +1567,10 @@ static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
 // Fills the phase table of R (adjoint = 0) or of its data adjoint (adjoint = 1: one phase per sub-pixel).
 // `panel` is the packed-weight buffer (may be null when only sizes are wanted); with `pack` the packing kernels
 // are launched.  Returns the panel size in floats and the largest per-phase N.
-static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* panel, IgParams& p, int* nmax_out,
+static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* panel, IgParams& p, int* nmax_out,
                      size_t* panel_floats_out, bool pack, hipStream_t st, PackBatch* batch_out = nullptr) {
+    // adjoint_fmt: bit 0 = direction (0: R, 1: its data adjoint), bit 1 = panel format (0: bf16 planes, 1: fp16-piece planes)
+    const int adjoint = adjoint_fmt & 1, fmt = (adjoint_fmt >> 1) & 1;
     size_t off = 0;
     int nmax = 0;
     p.nphase = 0;
@@ -1442,12 +1587,13 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
         pa.K = g.C * pa.TH * pa.TW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
         pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = pa.kh0 - g.pad_h; pa.dys = 1; pa.dx0 = pa.kw0 - g.pad_w; pa.dxs = 1;
         pa.dmin = tap_dmin(pa);
+        pa.fmt = fmt;
         batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
         ph.T = pa.TH * pa.TW;
         ph.oy0 = ph.ox0 = 0; ph.QH = g.OH; ph.QW = g.OW;
-        off = panel_floats(pa.rows, pa.ld);
+        off = panel_floats(pa.rows, pa.ld, fmt);
         nmax = g.B * g.OH * g.OW;
     } else {
         p.B = g.B; p.C = g.M; p.H = g.OH; p.W = g.OW; p.M = g.C; p.OH = g.H; p.OW = g.W;
@@ -1475,11 +1621,12 @@ static int conv_plan(const ConvGeom& g, int adjoint, const float* w, float* pane
                 pa.K = g.M * TH * TW; pa.rows = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.C, 32);
                 pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
                 pa.dmin = tap_dmin(pa);
+                pa.fmt = fmt;
                 batch.ph[p.nphase - 1] = pa;
                 phase_finish(ph, pa, pa.out);
                 ph.T = TH * TW;
                 ph.oy0 = py; ph.ox0 = px; ph.QH = QH; ph.QW = QW;
-                off += panel_floats(pa.rows, pa.ld);
+                off += panel_floats(pa.rows, pa.ld, fmt);
                 const int nph = g.B * QH * QW;
                 if (nph > nmax) nmax = nph;
             }
@@ -1532,8 +1679,10 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
     return LOCATE_OK;
 }
 
-LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, void* stream) {
+LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, void* stream) {
     LOCATE_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "locate_conv_pack_panels: bad arguments");
+    if (any_f16)        // fp16-piece panels: zero the absmax words the packing blocks fold their maxima into
+        pack_clear_jobs_kernel<<<(4 * n_jobs + 63) / 64, 64, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     pack_jobs_kernel<<<total_blocks, 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     LOCATE_LAUNCH_CHECK("locate_conv_pack_panels");
     pack_split_jobs_kernel<<<dim3(PACK_SPLIT_BLOCKS, n_jobs, 4), 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs));
@@ -1543,12 +1692,14 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
                      int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, unsigned* counters,
-                     int precision, hipStream_t st, const char* who) {
-    LOCATE_REQUIRE(precision == 0 || precision == 1, "%s: precision must be 0 (fp32-faithful) or 1 (bf16 operands)", who);
+                     int precision, const unsigned* in_absmax, hipStream_t st, const char* who) {
+    LOCATE_REQUIRE(precision >= 0 && precision <= 2, "%s: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)", who);
+    LOCATE_REQUIRE(precision != 2 || in_absmax, "%s: precision 2 needs the gathered tensor's absmax word", who);
     IgParams p;
     p.precision = precision;
+    p.b_absmax = in_absmax;
     int nmax = 0;
-    if (int e = conv_plan(g, adjoint, nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
+    if (int e = conv_plan(g, adjoint | (precision == 2 ? 2 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
     p.scale_bg = scale_bg; p.scale_stride = scale_stride;
@@ -1585,12 +1736,12 @@ LOCATE_API size_t locate_conv_counter_bytes(void) { return IG_MAX_COUNTERS * siz
 // tiles of mid-sized launches are combined inside the launch instead of by a second kernel.
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               void* workspace, void* counters, int precision, void* stream) {
+                               void* workspace, void* counters, int precision, const void* x_absmax, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
     return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
-                     static_cast<unsigned*>(counters), precision, as_stream(stream), "locate_conv_fwd");
+                     static_cast<unsigned*>(counters), precision, static_cast<const unsigned*>(x_absmax), as_stream(stream), "locate_conv_fwd");
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw
@@ -1598,12 +1749,13 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 void* workspace, void* counters, int precision, void* stream) {
+                                 void* workspace, void* counters, int precision, const void* gy_absmax, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
     return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
-                     static_cast<float*>(workspace), static_cast<unsigned*>(counters), precision, as_stream(stream), "locate_conv_dgrad");
+                     static_cast<float*>(workspace), static_cast<unsigned*>(counters), precision, static_cast<const unsigned*>(gy_absmax),
+                     as_stream(stream), "locate_conv_dgrad");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1633,6 +1785,8 @@ struct WgParams {
     const float* w_ref;       // W_bar for the fused <G, W_bar> partial sums (nullable)
     const float* inv_scale;   // device scalar 1/sigma (nullable)
     double* partial;          // one double per block (nullable)
+    const unsigned* x_absmax; // fp16 pieces (NP = 2): largest magnitudes of x and of gy, AMAX_WORDS words of bit patterns each
+    const unsigned* g_absmax;
 };
 
 // n / d for 0 <= n < 2^31 as t = mulhi(n, mul); (t + ((n - t) >> s1)) >> s2   (Granlund-Montgomery)
@@ -1844,7 +1998,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
                                       // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
                                       // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
-template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands (see conv_igemm_bx6_kernel)
+template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands; NP = 2: two scaled fp16 pieces (see conv_igemm_bx6_kernel)
 __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BR = WGN * TN * 32;
@@ -1903,6 +2057,17 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         gs3 = ng > 3 ? p.inv_scale[3 * p.gscale_stride] : 1.0f;
     }
 
+    // fp16 pieces: both operands go through powers of two into fp16's range (gy after its per-call 1/sigma, whose largest
+    // value bounds the product), the exact inverses are applied to the accumulators after the loop
+    float g_scale = 1.0f, x_scale = 1.0f, g_unscale = 1.0f, x_unscale = 1.0f;
+    if constexpr (NP == 2) {
+        const float gmax = __uint_as_float(absmax_read(p.g_absmax)) * fmaxf(fmaxf(gs0, gs1), fmaxf(gs2, gs3));
+        const int kg_ = f16_scale_exp(__float_as_uint(gmax) + (p.gscale_bg > 0 ? 0x00800000u : 0u));    // (product rounded: one binade of slack)
+        const int kx_ = f16_scale_exp(absmax_read(p.x_absmax));
+        g_scale = pow2f(kg_); g_unscale = pow2f(-kg_);
+        x_scale = pow2f(kx_); x_unscale = pow2f(-kx_);
+    }
+
     float2 greg[G_PT], xreg[X_PT];
     auto load_tiles = [&](int nb) {
         const int n = nb + 2 * np;                 // even; n + 1 is in the same image and output row
@@ -1943,7 +2108,12 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
-            if constexpr (NP == 3) {
+            if constexpr (NP == 2) {
+                unsigned h, l;
+                split2_f16_pair(greg[i].x * gsc * g_scale, greg[i].y * gsc * g_scale, h, l);
+                Gs[buf][0][sub + 32 * i][wcol] = h;
+                Gs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else if constexpr (NP == 3) {
                 unsigned h, m, l;
                 split3_trunc_pair(greg[i].x * gsc, greg[i].y * gsc, h, m, l);
                 Gs[buf][0][sub + 32 * i][wcol] = h;
@@ -1955,7 +2125,12 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         }
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
-            if constexpr (NP == 3) {
+            if constexpr (NP == 2) {
+                unsigned h, l;
+                split2_f16_pair(xreg[i].x * x_scale, xreg[i].y * x_scale, h, l);
+                Xs[buf][0][sub + 32 * i][wcol] = h;
+                Xs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else if constexpr (NP == 3) {
                 unsigned h, m, l;
                 split3_trunc_pair(xreg[i].x, xreg[i].y, h, m, l);
                 Xs[buf][0][sub + 32 * i][wcol] = h;
@@ -1978,26 +2153,31 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         load_tiles(n_begin + WB_BK);                 // beyond n_end: every lane masked, nothing is read
     }
     __syncthreads();
-    constexpr int PROD = NP == 3 ? 6 : 1;
+    constexpr int PROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
     constexpr int NMF = TM * TN * PROD, HALF = NMF / 2;
+    using frag_t = typename std::conditional<NP == 2, f16x8, bf16x8>::type;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        bf16x8 a[TM][NP], b[TN][NP];
+        frag_t a[TM][NP], b[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int base = (i * TN + j) * PROD;
-                    if constexpr (NP == 3) {
+                    if constexpr (NP == 2) {
+                        if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);   // l h
+                        if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);   // h l
+                        if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    } else if constexpr (NP == 3) {
                         if (base + 0 >= lo && base + 0 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);   // l h
                         if (base + 1 >= lo && base + 1 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);   // h l
                         if (base + 2 >= lo && base + 2 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
@@ -2017,6 +2197,14 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         __builtin_amdgcn_sched_barrier(0);
         mfmas(HALF, NMF);
         __syncthreads();
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * g_unscale) * x_unscale;
     }
     wgrad_epilogue<WGM, WGN, TM, TN>(p, acc, r0, m0, wm, wn, lane, wid, tid);
 }
@@ -2422,10 +2610,12 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
 // (stacked forwards; at most 4 groups; w_ref / inner_partial must then be null - see locate_sn_group_dsigma).
 LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                                  const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
-                                 double* inner_partial, void* workspace, int precision, void* stream) {
+                                 double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
+                                 void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
-    LOCATE_REQUIRE(precision == 0 || precision == 1, "locate_conv_wgrad: precision must be 0 (fp32-faithful) or 1 (bf16 operands)");
+    LOCATE_REQUIRE(precision >= 0 && precision <= 2, "locate_conv_wgrad: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)");
+    LOCATE_REQUIRE(precision != 2 || (x_absmax && gy_absmax), "locate_conv_wgrad: precision 2 needs the absmax words of x and gy");
     LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
     LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
     LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
@@ -2487,6 +2677,8 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     const bool direct = nsplit == 1;
     const bool grouped = scale_group_batch > 0;
     p.gscale_bg = scale_group_batch; p.gscale_stride = scale_stride;
+    p.x_absmax = static_cast<const unsigned*>(x_absmax);
+    p.g_absmax = static_cast<const unsigned*>(gy_absmax);
     p.direct_out = direct ? gw : nullptr;
     p.w_ref = direct ? w_ref : nullptr;
     p.inv_scale = (direct || grouped) ? inv_scale : nullptr;
@@ -2502,6 +2694,11 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
         else conv_wgrad_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
+    } else if (pairs_ok && precision == 2 && !path_disabled("wbx6")) {
+        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 2><<<grid, 256, 0, st>>>(p);
+        else conv_wgrad_bx6_kernel<1, 4, 1, 1, 2><<<grid, 256, 0, st>>>(p);
     } else if (pairs_ok && !path_disabled("wbx6")) {
         if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 3><<<grid, 256, 0, st>>>(p);

@@ -14,7 +14,10 @@
 // reference's 1/cosh^2 overflows to 1/inf = 0 (activation.py:24-26) - same limit, finite result.
 // ---------------------------------------------------------------------------------------------
 template <int OP>  // 0 roottanh, 1 tanh
-__global__ void __launch_bounds__(256) unary_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+__global__ void __launch_bounds__(256) unary_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                        unsigned* __restrict__ absmax) {
+    __shared__ float amax_scratch[16];
+    float am = 0.0f;
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -27,15 +30,23 @@ __global__ void __launch_bounds__(256) unary_fwd_kernel(const float* __restrict_
             o.x = tanhf(v.x); o.y = tanhf(v.y); o.z = tanhf(v.z); o.w = tanhf(v.w);
         }
         y4[i] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        y[i] = OP == 0 ? roottanh_f(x[i]) : tanhf(x[i]);
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float o = OP == 0 ? roottanh_f(x[i]) : tanhf(x[i]);
+        y[i] = o;
+        am = fmaxf(am, fabsf(o));
+    }
+    if (absmax) absmax_publish(am, amax_scratch, absmax);      // largest |y| for the fp16-piece contractions (common.h)
 }
 
 // OP 0: gx = g * roottanh'(a) with a = forward INPUT.   OP 1: gx = g * (1 - a^2) with a = forward OUTPUT.
 template <int OP>
 __global__ void __launch_bounds__(256) unary_bwd_kernel(const float* __restrict__ a, const float* __restrict__ g,
-                                                        float* __restrict__ gx, int64_t n, int accumulate) {
+                                                        float* __restrict__ gx, int64_t n, int accumulate,
+                                                        unsigned* __restrict__ absmax) {
+    __shared__ float amax_scratch[16];
+    float am = 0.0f;
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -55,28 +66,32 @@ __global__ void __launch_bounds__(256) unary_bwd_kernel(const float* __restrict_
             o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
         }
         o4[i] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float o = OP == 0 ? roottanh_grad_f(a[i], g[i]) : g[i] * (1.0f - a[i] * a[i]);
-        gx[i] = accumulate ? gx[i] + o : o;
+        float o = OP == 0 ? roottanh_grad_f(a[i], g[i]) : g[i] * (1.0f - a[i] * a[i]);
+        o = accumulate ? gx[i] + o : o;
+        gx[i] = o;
+        am = fmaxf(am, fabsf(o));
     }
+    if (absmax) absmax_publish(am, amax_scratch, absmax);      // largest |gx| (after accumulation) for the fp16-piece contractions
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-LOCATE_API int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+LOCATE_API int locate_roottanh_fwd(const float* x, float* y, int64_t n, void* absmax, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_roottanh_fwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_fwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n);
+    unary_fwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n, static_cast<unsigned*>(absmax));
     LOCATE_LAUNCH_CHECK("locate_roottanh_fwd");
     return LOCATE_OK;
 }
 
 // accumulate != 0: gx += ... (the second backward kernel of a forked tensor, see ops.fork)
-LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* stream) {
+LOCATE_API int locate_roottanh_bwd(const float* x, const float* gy, float* gx, int64_t n, int accumulate, void* absmax, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(gy) && aligned16(gx), "locate_roottanh_bwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_bwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, gy, gx, n, accumulate);
+    unary_bwd_kernel<0><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, gy, gx, n, accumulate, static_cast<unsigned*>(absmax));
     LOCATE_LAUNCH_CHECK("locate_roottanh_bwd");
     return LOCATE_OK;
 }
@@ -120,10 +135,28 @@ LOCATE_API int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_r
     return LOCATE_OK;
 }
 
+LOCATE_API int locate_absmax_words(void) { return AMAX_WORDS; }
+
+// largest magnitude of x folded into the AMAX_WORDS words at slot (atomic max on the bit patterns; the caller zeroes them first)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ slot) {
+    __shared__ float scratch[16];
+    float m = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+    absmax_publish(m, scratch, slot);
+}
+
+LOCATE_API int locate_absmax(const float* x, int64_t n, void* slot, void* stream) {
+    LOCATE_REQUIRE(x && slot && n > 0, "locate_absmax: bad arguments");
+    absmax_kernel<<<stream_grid(n, 2048), 256, 0, as_stream(stream)>>>(x, n, static_cast<unsigned*>(slot));
+    LOCATE_LAUNCH_CHECK("locate_absmax");
+    return LOCATE_OK;
+}
+
 LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(x) && aligned16(y), "locate_tanh_fwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_fwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n);
+    unary_fwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(x, y, n, nullptr);
     LOCATE_LAUNCH_CHECK("locate_tanh_fwd");
     return LOCATE_OK;
 }
@@ -131,7 +164,7 @@ LOCATE_API int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream
 LOCATE_API int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream) {
     LOCATE_REQUIRE(n >= 0 && aligned16(y) && aligned16(gy) && aligned16(gx), "locate_tanh_bwd: bad size or unaligned pointer");
     if (n == 0) return LOCATE_OK;
-    unary_bwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(y, gy, gx, n, 0);
+    unary_bwd_kernel<1><<<stream_grid(n, 1024), 256, 0, as_stream(stream)>>>(y, gy, gx, n, 0, nullptr);
     LOCATE_LAUNCH_CHECK("locate_tanh_bwd");
     return LOCATE_OK;
 }

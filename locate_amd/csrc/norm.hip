@@ -101,8 +101,10 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
                                                                int npartial, float* __restrict__ stats_out,
                                                                const float* __restrict__ scale, int scale_per_sample,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               int64_t planes_g, int C, int hw) {
+                                                               int64_t planes_g, int C, int hw, unsigned* __restrict__ absmax) {
     __shared__ double scratch[16];
+    __shared__ float amax_scratch[16];
+    float am = 0.0f;
     const int grp = blockIdx.y;
     const int64_t n = planes_g * hw;                 // elements of one group
     float mu, s;
@@ -131,16 +133,20 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
             o.z = fmaf(v.z - mu, ys, b); o.w = fmaf(v.w - mu, ys, b);
             if (ACT) { o.x = roottanh_f(o.x); o.y = roottanh_f(o.y); o.z = roottanh_f(o.z); o.w = roottanh_f(o.w); }
             o4[i] = o;
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
-        return;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int64_t p = plane0 + i / hw;
+            const int c = (int)(p % C);
+            const float y = scale[scale_per_sample ? p : c];
+            float o = fmaf(x[i] - mu, y * inv_s, bias[c]);
+            o = ACT ? roottanh_f(o) : o;
+            out[i] = o;
+            am = fmaxf(am, fabsf(o));
+        }
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t p = plane0 + i / hw;
-        const int c = (int)(p % C);
-        const float y = scale[scale_per_sample ? p : c];
-        const float o = fmaf(x[i] - mu, y * inv_s, bias[c]);
-        out[i] = ACT ? roottanh_f(o) : o;
-    }
+    if (absmax) absmax_publish(am, amax_scratch, absmax);      // largest |out| over all groups, for the fp16-piece contractions
 }
 
 // out = (x - mean(x)) * scale / std(x) + bias  (with_act = 0), or RootTanh of it (with_act = 1; the plain value is not
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(256) norm_apply_fused_kernel(const float* __re
 // same group count) - the statistics pass is then skipped.
 LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per_sample, const float* bias, float* out,
                                int with_act, float* stats_out, int B, int C, int hw, int groups, void* workspace,
-                               const double* pre_partial, void* stream) {
+                               const double* pre_partial, void* absmax, void* stream) {
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && (workspace || pre_partial) && stats_out && out, "locate_norm_fwd: bad arguments");
     LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_fwd: bad group count %d for batch %d", groups, B);
     LOCATE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "locate_norm_fwd: x must be 16-byte aligned");
@@ -168,9 +174,11 @@ LOCATE_API int locate_norm_fwd(const float* x, const float* scale, int scale_per
     }
     const dim3 grid(stream_grid(n_g, 1024), groups);
     if (with_act)
-        norm_apply_fused_kernel<true><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw);
+        norm_apply_fused_kernel<true><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw,
+                                                            static_cast<unsigned*>(absmax));
     else
-        norm_apply_fused_kernel<false><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw);
+        norm_apply_fused_kernel<false><<<grid, 256, 0, st>>>(x, partial, np, stats_out, scale, scale_per_sample, bias, out, planes_g, C, hw,
+                                                             static_cast<unsigned*>(absmax));
     LOCATE_LAUNCH_CHECK("locate_norm_fwd(apply)");
     return LOCATE_OK;
 }

@@ -131,6 +131,7 @@ class _NetBase(nn.Module):
                 self._sn_queue.append((sig, wvs))
 
     def _sn_prologue(self, stacked=1):
+        ops.AMAX.new_pass()          # this forward's largest-magnitude words come from a block of their own
         if stacked > 1 and not self.batched_spectral_norm:
             raise RuntimeError("a forward over stacked calls needs batched_spectral_norm = True")
         if self.batched_spectral_norm:

@@ -39,15 +39,75 @@ def _p(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# largest-magnitude words for the contractions' fp16-piece form (csrc/conv.hip, precision 2)
+# ------------------------------------------------------------------------------------------------
+class _AmaxArena:
+    """The fp32-faithful contractions run fastest with both operands split into TWO fp16 pieces (three MFMAs per slice instead
+    of the six of the three-piece bf16 split) - which needs every operand tensor scaled by a power of two into fp16's range,
+    i.e. its largest magnitude known when the consumer starts.  The kernels that PRODUCE a contraction's operand (norm + RootTanh
+    in front of a conv stage, RootTanh's backward in front of its input / weight gradients) fold that maximum into one device
+    word - an atomic max on the bit pattern: order-independent, so deterministic - and the word rides along on the tensor
+    (`_locate_amax`).  A tensor without one (any other producer, a gradient autograd had to sum, a non-contiguous view that
+    was copied) simply takes the six-product path: same fp32-level results, nothing is ever guessed.
+
+    Words come from small zeroed blocks, each handed out once (never reused: no aliasing between passes or networks); a new
+    block costs one fill launch per forward / backward pass."""
+    SLOTS = 32
+
+    def __init__(self):
+        self.block, self.used = None, 0
+        self.enabled = True
+        self.words = None            # words per tensor (locate_absmax_words: producers spread their atomics over them)
+
+    def new_pass(self):
+        self.block = None
+
+    def slot(self, device):
+        if not self.enabled:
+            return None
+        if self.words is None:
+            self.words = lib().locate_absmax_words()
+        if self.block is None or self.used >= self.SLOTS or self.block.device != device:
+            self.block = torch.zeros(self.SLOTS * self.words, dtype=torch.int32, device=device)
+            self.used = 0
+        s = self.block[self.used * self.words:(self.used + 1) * self.words]
+        self.used += 1
+        return s
+
+
+AMAX = _AmaxArena()
+# contractions below this much work per launch are latency-bound - nothing to gain from fewer matrix instructions (measured on the
+# whole step, one box: threshold 0.5 / 1 / 2.45 / 3 / 12 GFLOP -> 10.45 / 10.50 / 10.55 / 10.59 / 10.61 ms, form off 11.06)
+F16_MIN_FLOPS = 0.5e9
+
+
+F16_CALLS = {"fwd": 0, "dgrad": 0, "wgrad": 0}      # launches that took the fp16-piece form (tests check the path is live)
+
+
+def _amax_of(t):
+    return getattr(t, "_locate_amax", None) if AMAX.enabled else None
+
+
+def tag_amax(t):
+    """Computes t's largest-magnitude word with a pass of its own and attaches it (tests, tools; the hot path gets the word from
+    the kernel that produces the tensor)."""
+    slot = AMAX.slot(t.device)
+    if slot is not None:
+        check(lib().locate_absmax(_p(_c(t)), t.numel(), _p(slot), _stream()), "locate_absmax")
+        t._locate_amax = slot
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
 # RootTanh / tanh
 # ------------------------------------------------------------------------------------------------
 class RootTanhFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, slot=None):
+    def forward(ctx, x, slot=None, amax=None):
         ctx.slot = slot
         x = _c(x, "root_tanh input")
         y = torch.empty_like(x)
-        check(lib().locate_roottanh_fwd(_p(x), _p(y), x.numel(), _stream()), "locate_roottanh_fwd")
+        check(lib().locate_roottanh_fwd(_p(x), _p(y), x.numel(), _p(amax), _stream()), "locate_roottanh_fwd")
         ctx.save_for_backward(x)
         return y
 
@@ -56,8 +116,13 @@ class RootTanhFn(torch.autograd.Function):
         x, = ctx.saved_tensors
         g = _c(g)
         gx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
-        check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), acc, _stream()), "locate_roottanh_bwd")
-        return gx, None
+        # a fresh buffer of its own: its largest magnitude rides along for the contraction that consumes it (a shared fan-out
+        # buffer does not get one - the other branch still adds into it)
+        amax = AMAX.slot(x.device) if ctx.slot is None else None
+        check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), acc, _p(amax), _stream()), "locate_roottanh_bwd")
+        if amax is not None:
+            gx._locate_amax = amax
+        return gx, None, None
 
 
 class TanhFn(torch.autograd.Function):
@@ -107,7 +172,13 @@ class ActCatFn(torch.autograd.Function):
 
 
 def root_tanh(x):
-    return RootTanhFn.apply(x, _slot_of(x) if x.is_contiguous() else None)
+    # the activation in front of a conv: its output's largest magnitude rides along for the contraction's fp16-piece form
+    # (only worth a word where a contraction of F16_MIN_FLOPS could follow: 4-d maps, not the style chain's rows)
+    amax = AMAX.slot(x.device) if x.dim() >= 3 and x.numel() >= (1 << 16) else None
+    y = RootTanhFn.apply(x, _slot_of(x) if x.is_contiguous() else None, amax)
+    if amax is not None:
+        y._locate_amax = amax
+    return y
 tanh = TanhFn.apply
 act_cat = ActCatFn.apply
 
@@ -169,6 +240,7 @@ class Runtime:
         self._side = None
         self._side_results = []
         self._keep = []
+        AMAX.new_pass()
         self._fin_dots, self._fin_rank1, self._fin_sums = [], [], []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
@@ -431,7 +503,7 @@ class InPlaceNormFn(torch.autograd.Function):
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
-    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None, slot=None):
+    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None, slot=None, amax=None):
         ctx.slot = slot
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
@@ -448,7 +520,7 @@ class InPlaceNormFn(torch.autograd.Function):
         ws = _ws(L.locate_norm_stats_workspace_bytes(), x.device) if pre_partial is None else None
         out = torch.empty_like(x)       # RootTanh(norm(x)) when with_act, else norm(x)
         check(L.locate_norm_fwd(_p(x), _p(scale_c), int(per_sample), _p(bias_c), _p(out), int(bool(with_act)), _p(stats), B, C, hw,
-                                groups, _p(ws), _p(pre_partial), st), "locate_norm_fwd")
+                                groups, _p(ws), _p(pre_partial), _p(amax), st), "locate_norm_fwd")
         ctx.per_sample, ctx.with_act, ctx.groups = per_sample, bool(with_act), groups
         ctx.scale_shape, ctx.bias_shape = scale.shape, bias.shape
         ctx.save_for_backward(x, scale_c, bias_c, stats)
@@ -468,7 +540,7 @@ class InPlaceNormFn(torch.autograd.Function):
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
                                 _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), acc, st), "locate_norm_bwd")
-        return dx, dscale, dbias, None, None, None, None
+        return dx, dscale, dbias, None, None, None, None, None
 
 
 def inplace_norm(x, scale, bias, with_act=False, runtime=None):
@@ -476,7 +548,13 @@ def inplace_norm(x, scale, bias, with_act=False, runtime=None):
     # statistics partials left by the gate kernel that produced x (residual_gate): usable if taken for the same grouping
     pre = getattr(x, "_locate_stats", None)
     pre_partial = pre[0] if (pre is not None and pre[1] == groups and x.is_contiguous()) else None
-    return InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None)
+    # the output's largest magnitude for the fp16-piece form of the contraction that consumes it (a conv stage behind
+    # norm + RootTanh, the position gate's first 1x1 conv behind a plain norm)
+    amax = AMAX.slot(x.device) if x.numel() >= (1 << 16) else None
+    out = InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None, amax)
+    if amax is not None:
+        out._locate_amax = amax
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -829,7 +907,8 @@ def refresh_panels(params):
         if len(_PackPlans.cache) > 16:
             _PackPlans.cache.clear()
         _PackPlans.cache[sig] = plan
-    check(L.locate_conv_pack_panels(_p(plan[0]), plan[1], plan[2], _stream()), "locate_conv_pack_panels")
+    check(L.locate_conv_pack_panels(_p(plan[0]), plan[1], plan[2], int(any(key[0] & 2 for _, key, _, _ in stale)), _stream()),
+          "locate_conv_pack_panels")
     for w, key, buf, geom in stale:
         w.__dict__["_locate_panels"][key] = (w._version, buf, geom)
 
@@ -889,20 +968,36 @@ def _counters(owner, adjoint):
     return cache[key]
 
 
-def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0):
-    """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode."""
+def _flops(geom):
+    B, C, H, W, M, KH, KW, s_, ph, pw, OH, OW = geom
+    return 2.0 * B * OH * OW * M * C * KH * KW
+
+
+def _f16_ok(spec, geom, precision, *amax):
+    """The fp16-piece form of a fp32-faithful contraction: every gathered operand's largest magnitude known, and enough work
+    for the matrix instructions to matter."""
+    return precision == 0 and spec.mode == "dense" and all(a is not None for a in amax) and _flops(geom) >= F16_MIN_FLOPS
+
+
+def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0, amax=None):
+    """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode.
+    amax: x's largest-magnitude word, if its producer left one (fp16-piece form, panel format bit 2)."""
     L = lib()
     st = _stream()
     _, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
     if spec.mode == "dense":
+        f16 = _f16_ok(spec, geom, precision, amax)
+        prec, fmt, am = (2, 2, amax) if f16 else (precision, 0, None)
+        if f16:
+            F16_CALLS["fwd" if forward_of_r == (spec.kind == "conv") else "dgrad"] += 1
         if forward_of_r:
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
-            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                    _bs(y), _p(ws), _p(_counters(owner, 0)), precision, st), "locate_conv_fwd")
+            check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                    _bs(y), _p(ws), _p(_counters(owner, 0)), prec, _p(am), st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
-            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                      _bs(y), _p(ws), _p(_counters(owner, 1)), precision, st), "locate_conv_dgrad")
+            check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
+                                      _bs(y), _p(ws), _p(_counters(owner, 1)), prec, _p(am), st), "locate_conv_dgrad")
         return y
     if bias is not None:
         raise NotImplementedError("grouped convolutions carry no bias in the reference (libs/conv.py:15, libs/attention.py:18)")
@@ -918,27 +1013,30 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
     return y
 
 
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0):
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0, amax=None):
     """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
     y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision)
+    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision, amax)
 
 
-def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0):
+def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0, amax=None):
     """Gradient w.r.t. the layer input."""
     if spec.mode == "groupdot":
         gy = gy.contiguous()
-    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like), precision)
+    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like), precision, amax)
 
 
-def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0):
+def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0, amax_in=None, amax_out=None):
     """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>."""
     L = lib()
     st = _stream()
     if spec.mode == "dense":
         ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), xin.device)
+        f16 = _f16_ok(spec, geom, precision, amax_in, amax_out)
+        F16_CALLS["wgrad"] += int(f16)
         check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial),
-                                  _p(ws), precision, st), "locate_conv_wgrad")
+                                  _p(ws), 2 if f16 else precision, _p(amax_in) if f16 else None, _p(amax_out) if f16 else None, st),
+              "locate_conv_wgrad")
     elif spec.mode == "depthwise":
         ws = _ws(L.locate_dwconv_wgrad_workspace_bytes(garr), xin.device)
         check(L.locate_dwconv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst,
@@ -959,7 +1057,7 @@ def _weight_grad_partials(spec, geom, garr):
     return L.locate_groupdot_wgrad_partials(geom[1], geom[2])
 
 
-def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v):
+def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v, amax_x=None, amax_gy=None):
     """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
     (Runtime.defer_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side).
     With rt.defer_finalisers the rank-1 term, du and dsigma (and the stacked calls' dots) are only QUEUED here: the returned
@@ -969,6 +1067,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
     gw = torch.empty_like(w)
     xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
+    am_in, am_out = (amax_x, amax_gy) if spec.kind == "conv" else (amax_gy, amax_x)
     h = w.shape[0]
     wd = w.numel() // h
     u, v = u_param.detach(), v_param.detach()
@@ -976,7 +1075,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
-        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision)
+        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision, am_in, am_out)
         dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
         Bn, Mn = gy.shape[0], gy.shape[1]
         plane = gy.numel() // (Bn * Mn)
@@ -996,7 +1095,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     # then the rank-1 spectral-norm correction in place
     npart = _weight_grad_partials(spec, geom, garr)
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
-    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision)
+    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision, am_in, am_out)
     dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
     if rt.defer_finalisers:
         rt.queue_sn_rank1(partial, npart, 0, sigma, 0, u, v, wv, 0, gw, gu, dsig, h, wd)
@@ -1037,7 +1136,8 @@ class SNConvFn(torch.autograd.Function):
         garr = _geom(geom)
         b = _c(bias) if bias is not None else None
         rt = rt or DEFAULT_RUNTIME
-        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision)
+        ctx.amax_x = _amax_of(x)
+        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
         ctx.groups = groups
         if groups > 1:
@@ -1059,20 +1159,23 @@ class SNConvFn(torch.autograd.Function):
             y = bsaved = None
         spec, garr = ctx.spec, _geom(ctx.geom)
         gy = _dense(gy, "conv output gradient")
+        amax_gy = _amax_of(gy)
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
         gx = gw = gu = gb = None
         if need_x:
-            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma, ctx.rt.precision)
+            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma, ctx.rt.precision, amax_gy)
         if need_w or need_u or need_v:
             rt = ctx.rt
             side = rt.weight_grad_stream
             late = side is not None or rt.defer_finalisers     # the gradients bypass autograd: assigned at the end of the pass
             if side is None:
-                sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v,
+                                             ctx.amax_x, amax_gy)
             else:
                 side.wait_stream(torch.cuda.current_stream())        # gy (and x) are complete on the pass's stream
                 with torch.cuda.stream(side):
-                    sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v)
+                    sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v,
+                                                 ctx.amax_x, amax_gy)
                 rt._side = side
             if late:
                 rt._keep.append((x, gy, y, bsaved, w, sigma, wv))

@@ -482,7 +482,7 @@ def gen_f64():
     build and the same inputs run twice through the REFERENCE, once as shipped (fp32) and once with both networks converted
     to float64 (`module.double()`, `G.noise.double()`, double inputs).  Stored: every gate's d(gamma) (merge.py:33-38, a sum
     with heavy cancellation) from both runs, the losses and the consistency penalty (grad_penalty.py:1-2) from both runs,
-    and the float64 gradient norms of every tensor.  The GPU tests then hold the kernels to a multiple of
+    the gradient norms and the post-optimizer-step parameter norms of every tensor from both runs.  The GPU tests then hold the kernels to a multiple of
     |ref32 - ref64| - the deviation the reference shows against itself - instead of to a bound derived from the build."""
     import warnings
     import torch
@@ -512,6 +512,11 @@ def gen_f64():
             d["%s/%s/gamma_grads" % (tag, net)] = np.array([float(gr[k].double().sum()) for k in gam])
             d["%s/%s/grad_keys" % (tag, net)] = np.array(list(gr.keys()))
             d["%s/%s/grad_norms" % (tag, net)] = np.array([float(v.double().norm()) for v in gr.values()])
+        # post-optimizer-step norms: the first Nadam steps move an element by lr * g / (|g| + 1e-8) - a sign-like function of
+        # the gradient, so elements whose gradient is at rounding-noise level land differently in the two precisions
+        for net, sd in (("D", rec["d_sd_post_step"]), ("G", rec["g_sd_post_step"])):
+            d["%s/%s/post_keys" % (tag, net)] = np.array(list(sd.keys()))
+            d["%s/%s/post_norms" % (tag, net)] = np.array([float(v.double().norm()) for v in sd.values()])
     _save(name + "_f64", d)
 
 

@@ -341,6 +341,39 @@ def test_conv_igemm_vs_cpu(kind, cin, cout, k, s, p, B, H, W):
     assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
 
 
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,B,H,W", CONV_CASES)
+def test_conv_fp16_pieces_vs_cpu(kind, cin, cout, k, s, p, B, H, W, monkeypatch):
+    """The same comparison with the contractions in their fp16-piece form (two scaled fp16 pieces per operand, three MFMAs per
+    slice; csrc/conv.hip precision 2) - held to the SAME bounds as the three-piece bf16 form above.  The largest-magnitude
+    words that select this form normally come from the producing kernels; here they are attached to the raw test tensors, and
+    the work threshold is lifted so that every geometry takes the path."""
+    from locate_amd import SpectralNorm, ops
+    from oracle import locate_oracle as O
+    monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0)
+    torch.manual_seed(cin * 1000 + cout + k)
+    nn = torch.nn
+    inner = (nn.Conv2d if kind == "conv" else nn.ConvTranspose2d)(cin, cout, k, stride=s, padding=p, bias=False)
+    mod = SpectralNorm(inner)
+    sd = {kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(B, cin, H, W) * 3.0
+    P = O.make_params(sd)
+    xr = x.clone().requires_grad_(True)
+    w = O.sn_weight(P, "module.")
+    yr = F.conv2d(xr, w, None, s, p) if kind == "conv" else F.conv_transpose2d(xr, w, None, s, p)
+    g = torch.randn_like(yr) * 1e-4          # gradient-sized values: far below fp16's normal range without the scaling
+    yr.backward(g)
+    mod = mod.to(dev())
+    xg = ops.tag_amax(x.to(dev()).requires_grad_(True))
+    before = dict(ops.F16_CALLS)
+    yg = mod(xg)
+    yg.backward(ops.tag_amax(g.to(dev())))
+    assert all(ops.F16_CALLS[kk] == before[kk] + 1 for kk in ("fwd", "dgrad", "wgrad")), (before, ops.F16_CALLS)
+    assert_close(yg.cpu(), yr, 2e-5, "y")
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
+    assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
+    assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
+
+
 GROUPED_CASES = [
     # kind, Cin, mult, k, stride, pad, B, H, W        (groups = Cin: the SEPARABLE switch, libs/conv.py:17)
     ("conv", 3, 1, 5, 2, 2, 4, 16, 16),        # D stem conv_0

@@ -286,3 +286,26 @@ def test_oracle_full_architectures_vs_reference_record(name, S, B, ff, switches)
         for k in keys:
             g = float(got[k].double().norm())
             assert abs(g - want[k]) <= 2e-4 * max(want[k], 1e-3 * scale), (tag, k, g, want[k])
+
+
+@pytest.mark.parametrize("name", ["g11_config1", "g12_config3_128", "g14_config2_64", "g13_256_narrow", "g20_256_full"])
+def test_float64_reference_records_are_the_same_run(name):
+    """The `_f64` records (oracle/gen_golden.py f64: the reference run in fp32 AND with both networks converted to float64) are
+    taken on the same seeded build and inputs as the base record: their fp32 half reproduces the base record's numbers, and the
+    float64 half sits within the fp32 noise the survey measured (gradients <= 1.3e-5 of the largest,
+    ill-conditioned scalars aside)."""
+    import os
+    from conftest import GOLDEN_DIR
+    if not os.path.exists(os.path.join(GOLDEN_DIR, name + "_f64.npz")):
+        pytest.skip("no float64 record for " + name)
+    z, z64 = load_golden(name), load_golden(name + "_f64")
+    np.testing.assert_array_equal(z["after_build_rng_check"], z64["after_build_rng_check"])
+    for k in ("d_error", "penalty", "g_error"):
+        assert abs(float(z64["f32/" + k]) - float(z[k])) <= 1e-12 + 1e-6 * abs(float(z[k])), k
+        assert abs(float(z64["f64/" + k]) - float(z[k])) <= 1e-4 * abs(float(z[k])), k
+    for tag in ("D", "G"):
+        assert z64["f32/%s/grad_keys" % tag].tolist() == z[tag + "/grad_keys"].tolist()
+        np.testing.assert_allclose(z64["f32/%s/grad_norms" % tag], z[tag + "/grad_norms"], rtol=1e-12)
+        np.testing.assert_allclose(z64["f32/%s/post_norms" % tag], z[tag + "/post_norms"], rtol=1e-12)
+        a, b = z64["f32/%s/grad_norms" % tag], z64["f64/%s/grad_norms" % tag]
+        assert float(np.max(np.abs(a - b)) / np.max(b)) <= 1e-4, tag

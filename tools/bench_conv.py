@@ -55,6 +55,7 @@ def time_it(fn, reps):
     return e0.elapsed_time(e1) / (3 * reps)
 
 
+CHECK = False          # --check: forward / input gradient against a float64 CPU convolution
 ZEROS = False          # --zeros: all-zero operands (the chip holds a higher clock on them: separates clock-bound from issue-bound)
 
 
@@ -79,10 +80,16 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
     gx = torch.empty_like(x)
     gw = torch.empty_like(w)
     one = torch.ones(1, device=dev)
-    pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0), 16), dtype=torch.uint8, device=dev)
-    pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1), 16), dtype=torch.uint8, device=dev)
-    check(L.locate_conv_pack_panel(garr, 0, w.data_ptr(), pan0.data_ptr(), S()))
-    check(L.locate_conv_pack_panel(garr, 1, w.data_ptr(), pan1.data_ptr(), S()))
+    fmt = 2 if prec == 2 else 0          # panel format bit: fp16-piece planes
+    pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0 | fmt), 16), dtype=torch.uint8, device=dev)
+    pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1 | fmt), 16), dtype=torch.uint8, device=dev)
+    check(L.locate_conv_pack_panel(garr, 0 | fmt, w.data_ptr(), pan0.data_ptr(), S()))
+    check(L.locate_conv_pack_panel(garr, 1 | fmt, w.data_ptr(), pan1.data_ptr(), S()))
+    nw = L.locate_absmax_words()
+    amax = torch.zeros(2 * nw, dtype=torch.int32, device=dev)       # absmax words of x and gy
+    check(L.locate_absmax(x.data_ptr(), x.numel(), amax[0:].data_ptr(), S()))
+    check(L.locate_absmax(gy.data_ptr(), gy.numel(), amax[nw:].data_ptr(), S()))
+    slot = {x.data_ptr(): amax[0:].data_ptr(), gy.data_ptr(): amax[nw:].data_ptr()}
     ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
     ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
     part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
@@ -92,22 +99,42 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
 
     def r_fwd(inp, out):      # R forward
         check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, S()))
+                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, S()))
 
     def r_dgrad(inp, out):    # R data adjoint
         check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, S()))
+                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, S()))
 
     if kind == "conv":
         fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
         wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
-                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, S()))
+                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec,
+                                                slot[x.data_ptr()] if prec == 2 else None, slot[gy.data_ptr()] if prec == 2 else None, S()))
         flops = 2.0 * B * out_shape[2] * out_shape[3] * cout * cin * kh * kw
     else:
         fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
         wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
-                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec, S()))
+                                                w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec,
+                                                slot[gy.data_ptr()] if prec == 2 else None, slot[x.data_ptr()] if prec == 2 else None, S()))
         flops = 2.0 * B * H * W * cout * cin * kh * kw        # every input pixel meets every tap once
+    if CHECK:
+        import torch.nn.functional as F
+        fwd(); dgr()
+        torch.cuda.synchronize()
+        xd, wd, gd = x.double().cpu(), w.double().cpu(), gy.double().cpu()
+        if kind == "conv":
+            yr = F.conv2d(xd, wd, None, s, (ph, pw))
+            gr = F.conv_transpose2d(gd, wd, None, s, (ph, pw), output_padding=(x.shape[2] - ((gd.shape[2] - 1) * s - 2 * ph + kh), x.shape[3] - ((gd.shape[3] - 1) * s - 2 * pw + kw)))
+        else:
+            yr = F.conv_transpose2d(xd, wd, None, s, (ph, pw))
+            gr = F.conv2d(gd, wd, None, s, (ph, pw))
+        wgr()
+        torch.cuda.synchronize()
+        xr, wr = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+        (F.conv2d(xr, wr, None, s, (ph, pw)) if kind == "conv" else F.conv_transpose2d(xr, wr, None, s, (ph, pw))).backward(gd)
+        print("    max |err| / max |ref|:  fwd %.2e   dgrad %.2e   wgrad %.2e" % (
+            float((y.double().cpu() - yr).abs().max() / yr.abs().max()), float((gx.double().cpu() - gr).abs().max() / gr.abs().max()),
+            float((gw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())))
     ms = [time_it(f, reps) for f in (fwd, dgr, wgr)]
     nbytes = 4.0 * (x.numel() + y.numel()) + 6.0 * w.numel()      # activations once each + the three bf16 weight planes
     return ms, flops, nbytes
@@ -121,9 +148,12 @@ def main():
     ap.add_argument("--no-counters", action="store_true", help="NULL arrival counters: split-K partial tiles summed by the reduction kernel")
     ap.add_argument("--shape", action="append", default=[], help="extra stage: kind,Cin,Cout,k,stride,pad,H,B (replaces the list)")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands")
+    ap.add_argument("--f16", action="store_true", help="fp32-faithful with two scaled fp16 pieces per operand (precision 2)")
+    ap.add_argument("--check", action="store_true", help="print the forward / input-gradient error against float64")
     args = ap.parse_args()
-    global ZEROS
+    global ZEROS, CHECK
     ZEROS = args.zeros
+    CHECK = args.check
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
     shapes = SHAPES
@@ -135,7 +165,7 @@ def main():
     for name, kind, cin, cout, k, s, p, H, B in shapes:
         if args.only and args.only not in name:
             continue
-        ms, flops, _ = bench_shape(kind, cin, cout, k, k, s, p, p, B, H, H, args.reps, 1 if args.bf16 else 0, not args.no_counters)
+        ms, flops, _ = bench_shape(kind, cin, cout, k, k, s, p, p, B, H, H, args.reps, 2 if args.f16 else (1 if args.bf16 else 0), not args.no_counters)
         for i in range(3):
             tot[i] += ms[i]
         print("%-28s %s" % (name, "  ".join("%6.3f|%6.1f" % (m, flops / m / 1e9) for m in ms)), flush=True)

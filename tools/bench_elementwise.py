@@ -50,8 +50,8 @@ def main():
         hw, planes = H * W, Bn * C
         n = planes * hw
         x, g, y, gx = (torch.randn(shape, device=dev) for _ in range(4))
-        report("RootTanh", shape, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, st)),
-               lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, st)), 2 * n, 3 * n)
+        report("RootTanh", shape, lambda: check(L.locate_roottanh_fwd(P(x), P(y), n, None, st)),
+               lambda: check(L.locate_roottanh_bwd(P(x), P(g), P(gx), n, 0, None, st)), 2 * n, 3 * n)
         w, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         dw, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
         stats = torch.empty(2, device=dev)
@@ -59,7 +59,7 @@ def main():
         ws_b = torch.empty(max(L.locate_norm_bwd_workspace_bytes(Bn, C), 16), dtype=torch.uint8, device=dev)
         for act in (0, 1):
             report("InPlaceNorm" + (" + RootTanh" if act else ""), shape,
-                   lambda act=act: check(L.locate_norm_fwd(P(x), P(w), 0, P(b), P(y), act, P(stats), Bn, C, hw, 1, P(ws_f), None, st)),
+                   lambda act=act: check(L.locate_norm_fwd(P(x), P(w), 0, P(b), P(y), act, P(stats), Bn, C, hw, 1, P(ws_f), None, None, st)),
                    lambda act=act: check(L.locate_norm_bwd(P(x), P(g), P(stats), P(w), 0, P(b), act, P(gx), P(dw), P(db), Bn, C, hw, 1,
                                                            P(ws_b), 0, st)), 3 * n, 5 * n)    # statistics pass + apply | plane sums + dx
         a = torch.randn(shape, device=dev)
