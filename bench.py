@@ -42,11 +42,9 @@ def parse():
                          "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-wgrad-overlap", action="store_true",
-                    help="weight gradients in line with the backward pass (default on one GPU: on a second stream beside it; "
-                         "same values, -0.25 ms per step since the small launches stopped filling the chip)")
-    ap.add_argument("--dp-wgrad-overlap", action="store_true",
-                    help="also with --gpus N > 1 (correct - tests/test_gpu_dp.py - but unmeasured on RCCL: the only rehearsal "
-                         "possible here, two gloo ranks time-slicing ONE GPU, runs 17x slower with it, 3.3 s vs 0.19 s per step)")
+                    help="weight gradients in line with the backward pass (default, at any N: on a second stream beside it; same "
+                         "values, -0.25 ms per step; the data-parallel reducer picks such gradients up at the end of the pass - "
+                         "tests/test_gpu_dp.py)")
     ap.add_argument("--f16-min-gflop", type=float, default=None,
                     help="work threshold (GFLOP per launch) above which a fp32-faithful contraction takes its fp16-piece form "
                          "(default: locate_amd.ops.F16_MIN_FLOPS); a huge value turns the form off")
@@ -259,7 +257,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # LOCATE_DP_FORCE=1: the data-parallel machinery at world size 1 - process group, both reducers, the discriminator's cut
+    # backward, buckets on the side stream between the graph replays, RCCL all-reduce (a self-copy), unpack, join - as a one-rank
+    # rehearsal of the multi-GPU path on a single GPU (launch: python -m torch.distributed.run --nproc-per-node 1 bench.py)
+    force_dp = os.environ.get("LOCATE_DP_FORCE") == "1" and "RANK" in os.environ
+    dp = world > 1 or force_dp
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # rehearsal hook: LOCATE_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that) to exercise the
@@ -268,7 +271,7 @@ def main():
     local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    if dp:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -291,18 +294,18 @@ def main():
     G.set_precision(args.dtype)
     D.set_precision(args.dtype)
     red_g = red_d = None
-    if world > 1:
+    d_cut = None
+    if dp:
         broadcast_module_state(G, 0, extra_tensors=[G.noise])
         broadcast_module_state(D, 0)
         late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
         # the D-step's backward runs in two segments cut behind the discriminator's block 2 (maps >= 8x8 | <= 4x4): the deep
         # segment holds ~95 % of D's parameters and is on the wire while the high-resolution segment's backward runs
         d_cut = 3 if len(D.main[1].blocks) > 3 else None
-        red_g = GradAllReducer(G.parameters())
-        red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None)
+        red_g = GradAllReducer(G.parameters(), force=force_dp)
+        red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp)
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
-                     overlap_wgrad=(world == 1 and not args.no_wgrad_overlap) or args.dp_wgrad_overlap,
-                     d_cut=d_cut if world > 1 else None)
+                     overlap_wgrad=not args.no_wgrad_overlap, d_cut=d_cut)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)
@@ -318,7 +321,7 @@ def main():
         return step(latent, real, aug)
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -331,7 +334,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     comm = None
-    if world > 1:
+    if dp:
         # a few extra steps with HIP events around the exchange: how much of it hides behind backward work
         red_g.timing = red_d.timing = True
         for _ in range(5):
@@ -346,11 +349,11 @@ def main():
                 "note": "side-stream time of pack + RCCL all-reduce + unpack per optimizer step, and the part of it the compute "
                         "stream had to wait for; D's deep segment (blocks 3.. + head, ~95 % of its parameters) is sent while "
                         "the high-resolution segment's backward runs, G's widest layers are the last its backward produces"}
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if world > 1:
+    if dp:
         # replicas must still be identical after the timed steps (same averaged gradients, same deterministic kernels)
         chk = torch.stack([sum(p.detach().double().sum() for p in net.parameters()) for net in (G, D)])
         lo, hi = chk.clone(), chk.clone()
@@ -364,7 +367,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "images/sec (G+D step) 64x64 bs=64", "value": round(world * B * args.steps / elapsed, 2),
+            "metric": "images/sec (G+D step) %dx%d bs=%d" % (S, S, B), "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (contractions: exact 3 x bf16 operand splits on the bf16 MFMA, fp32 accumulate)" if args.dtype == "fp32" else
@@ -376,7 +379,8 @@ def main():
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" + ("" if args.no_overlap else ", G-step generator pass on a second stream")
                                   + (", weight gradients on a second stream" if step.overlap_wgrad else "")
-                                  + (" + bucketed RCCL all-reduce on a side stream between the graphs of the segmented backward" if world > 1 else ""))
+                                  + (" + bucketed RCCL all-reduce on a side stream between the graphs of the segmented backward" if dp else "")
+                                  + (" [LOCATE_DP_FORCE: one-rank rehearsal of the data-parallel path]" if force_dp and world == 1 else ""))
                                  if use_graph else "eager (all-reduce overlapped with backward)"},
             "losses": {"d_error": round(d_error, 5), "g_error": round(g_error, 5)},
         }
@@ -396,7 +400,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.step_only:
             line["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_steps)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -234,6 +234,14 @@ int locate_fin_sn_dots(const void* records, int n, void* stream);
 int locate_fin_sn_rank1(const void* records, int n, void* stream);
 int locate_fin_sums(const void* records, int n, void* stream);
 
+/* ---- gradient bucket pack / unpack of the data-parallel exchange (no reference counterpart: libs/config.py:10-11 is single
+ *      device).  tensors: DEVICE array of {float* grad; float* flat; int64 n} records (locate_multi_copy_record_bytes() = 24);
+ *      chunks: DEVICE (tensor index, chunk index) int pairs in pieces of locate_multi_copy_chunk_elems();
+ *      direction 0: flat <- grad;  1: grad <- flat * scale ---- */
+size_t locate_multi_copy_record_bytes(void);
+int locate_multi_copy_chunk_elems(void);
+int locate_multi_copy(const void* tensors, const void* chunks, int n_chunks, int direction, float scale, void* stream);
+
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */
 int locate_nadam_chunk_elems(void);

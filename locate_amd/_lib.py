@@ -92,6 +92,9 @@ PROTOTYPES = {
     "locate_fin_sn_rank1": (c_i, [c_p, c_i, c_p]),
     "locate_fin_sums": (c_i, [c_p, c_i, c_p]),
     "locate_gate_bwd_partials": (c_i, [c_i64, c_i]),
+    "locate_multi_copy_record_bytes": (c_sz, []),
+    "locate_multi_copy_chunk_elems": (c_i, []),
+    "locate_multi_copy": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
     "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),

@@ -16,7 +16,7 @@ LIB = os.path.join(CSRC, "liblocate_hip.so")
 LIB_DBG = os.path.join(CSRC, "liblocate_hip_dbg.so")
 DBG_SOURCES = ["conv.hip"]
 SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "grouped.hip",
-           "nadam.hip", "loss.hip", "finalise.hip"]
+           "nadam.hip", "loss.hip", "finalise.hip", "parallel.hip"]
 ARCH = "gfx950"
 
 

@@ -57,9 +57,19 @@ class GraphedTrainStep:
         self.sn_graph = None
         self.d_tail = None
 
+        # With a process group alive its watchdog thread polls the events of earlier collectives (hipEventQuery) at any time;
+        # under the default "global" capture mode that call, made by ANOTHER thread while this one captures, is an error that
+        # kills the process (found by the one-rank RCCL rehearsal, bench.py LOCATE_DP_FORCE=1).  "thread_local" restricts
+        # only the capturing thread; the captures themselves contain no collective (the exchange runs between the graphs).
+        import torch.distributed as dist
+        self._capture_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+        def graph_ctx(g, pool):
+            return torch.cuda.graph(g, pool=pool, stream=cap_stream, capture_error_mode=self._capture_mode)
+
         def capture(fn, pool=None):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool or self.pool, stream=cap_stream):
+            with graph_ctx(g, pool or self.pool):
                 out = fn()
             self.graphs.append(g)
             if isinstance(out, dict):
@@ -80,7 +90,7 @@ class GraphedTrainStep:
                 # the life of the graphs: they live in the second pool, which the G-step's generator pass also allocates from.
                 if step.stacked_d and getattr(step.dis, "batched_spectral_norm", False):
                     self.sn_graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.sn_graph, pool=self.pool_b, stream=cap_stream):
+                    with graph_ctx(self.sn_graph, self.pool_b):
                         step.dis.prefetch_spectral_norm(3)
                     self._keep.extend(step.dis._sn_queue)
                 if step.d_cut is not None:
@@ -88,7 +98,7 @@ class GraphedTrainStep:
                     # between them, so that it runs beside the second segment
                     capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated, segment=0))   # 1
                     self.d_tail = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.d_tail, pool=self.pool, stream=cap_stream):
+                    with graph_ctx(self.d_tail, self.pool):
                         step.d_forward_backward(lat, real_, aug_, segment=1)
                 else:
                     capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1

@@ -27,14 +27,18 @@ def broadcast_module_state(module, src=0, extra_tensors=()):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None, groups=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None, groups=None, reduce_op=None,
+                 force=False):
         """`late`: predicate (or collection) of parameters whose .grad is only assigned at the very end of the backward
         pass, outside autograd's accumulation (the spectral-norm v vectors, ops.Runtime._finalize_dv).  They get buckets
         of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients.
         `groups`: parameter collections in the order their gradients become complete when the backward pass is run in
         SEGMENTS (Discriminator.forward(cut_after=...)): buckets never span two groups, so `launch_group(i)` can send a
         finished segment's gradients while the next segment's backward is still running - the form the hipGraph replay
-        uses, where post-accumulate hooks do not exist."""
+        uses, where post-accumulate hooks do not exist.
+        `reduce_op`: "avg" (the collective averages: RCCL) or "sum" (sum, then scale by 1 / world on unpack: gloo); default by
+        backend.  `force`: run the whole exchange - buckets, side stream, collective, unpack - at world size 1 as well (a
+        one-rank rehearsal of the RCCL path on a single GPU; otherwise a lone rank skips it)."""
         self.params = [p for p in params]
         if late is None:
             is_late = [False] * len(self.params)
@@ -62,6 +66,7 @@ class GradAllReducer:
         self.n_groups = max(group_of) + 1 if group_of else 1
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1 or (bool(force) and dist.is_initialized())
         self.overlap = overlap
         self.bucket_bytes = bucket_bytes
         # reverse order ~ gradient production order
@@ -86,7 +91,11 @@ class GradAllReducer:
                     self.bucket_group.append(gi)
         # RCCL averages in the collective itself; gloo (CPU tests, single-GPU rehearsals) sums and scales afterwards
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
-        self._avg = backend == "nccl"
+        if reduce_op not in (None, "avg", "sum"):
+            raise ValueError("reduce_op must be 'avg' or 'sum'")
+        self._avg = (backend == "nccl") if reduce_op is None else reduce_op == "avg"
+        self._verified = set()     # (bucket, member tuple) combinations all ranks have been checked to agree on
+        self._copy_tables = {}     # (bucket, gradient / flat addresses) -> device tables of locate_multi_copy
         self.bucket_of = {}
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
@@ -114,7 +123,7 @@ class GradAllReducer:
     # ------------------------------------------------------------------------------------------
     def begin(self):
         """Call right before backward()."""
-        if self.world == 1:
+        if not self.enabled:
             return
         # hooks are (re)registered lazily: a tensor can only carry one once it requires grad, and the
         # discriminator's u/v only start to after the first G-step (reference main.py:172)
@@ -147,6 +156,7 @@ class GradAllReducer:
     def _launch(self, b):
         members = [i for i in self.buckets[b] if self.params[i].grad is not None]
         self._launched[b] = True
+        self._check_agreement(b, members)
         if not members:
             return
         grads = [self.params[i].grad for i in members]
@@ -165,12 +175,32 @@ class GradAllReducer:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record(self._side)
                     self._t_comm.append([ev, None])
-                self._pack(flat, grads)
+                self._pack(b, flat, grads)
                 work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         else:
-            self._pack(flat, grads)
+            self._pack(b, flat, grads)
             work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         self._handles.append((b, members, work))
+
+    def _check_agreement(self, b, members):
+        """Which parameters have a gradient is decided per rank (`grad is not None`); ranks that disagreed would exchange
+        buckets of different sizes - a hang or silent garbage.  The first time a bucket is sent with a given member list,
+        all ranks compare a digest of (bucket, members) with one tiny max-reduction of (h, -h): equal everywhere iff both
+        come back unchanged.  Every rank runs this check as the first collective of that bucket, so the check itself
+        always matches up; afterwards the combination is trusted."""
+        sig = (b, tuple(members))
+        if sig in self._verified:
+            return
+        import zlib
+        h = zlib.crc32(repr(sig).encode()) & 0x7fffffff
+        dev = self.params[self.buckets[b][0]].device if self.buckets[b] else torch.device("cpu")
+        t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        hi, lo = t.tolist()
+        if hi != h or -lo != h:
+            raise RuntimeError("data-parallel ranks disagree on which parameters of bucket %d carry a gradient (this rank: %d "
+                               "tensors): the replicas' backward passes differ" % (b, len(members)))
+        self._verified.add(sig)
 
     def _op(self):
         return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -178,7 +208,7 @@ class GradAllReducer:
     # ---- segment-driven form (hipGraph replay: no hooks) --------------------------------------------------------
     def begin_replay(self):
         """Before replaying a captured backward: nothing is launched yet."""
-        if self.world == 1:
+        if not self.enabled:
             return
         self._launched = [False] * len(self.buckets)
         self._handles = []
@@ -187,7 +217,7 @@ class GradAllReducer:
     def launch_group(self, gi):
         """Every gradient of segment group `gi` is complete on the current stream: send its buckets now, on the side
         stream (the next segment's backward, replayed right after this call, runs beside them)."""
-        if self.world == 1:
+        if not self.enabled:
             return
         for b, g in enumerate(self.bucket_group):
             if g == gi and not self._launched[b]:
@@ -202,14 +232,44 @@ class GradAllReducer:
             off += n
         return views
 
-    @classmethod
-    def _pack(cls, flat, grads):
-        # one multi-tensor launch per bucket instead of one copy per gradient (~140 tensors per network)
-        torch._foreach_copy_(cls._views(flat, grads), [g if g.is_contiguous() else g.contiguous() for g in grads])
+    def _copy_table(self, b, flat, grads):
+        """Device tables of locate_multi_copy for bucket b: one record per gradient {grad, its place in the bucket, n} and the
+        (tensor, chunk) list; cached on every address a record holds (stable under hipGraph replay, where the gradient
+        buffers live in the graphs' memory pool)."""
+        import struct
+        from ._lib import lib
+        key = (b, flat.data_ptr()) + tuple(g.data_ptr() for g in grads)
+        tab = self._copy_tables.get(key)
+        if tab is None:
+            L = lib()
+            assert L.locate_multi_copy_record_bytes() == 24
+            chunk = L.locate_multi_copy_chunk_elems()
+            rec, chunks, off = bytearray(), [], 0
+            for i, g in enumerate(grads):
+                rec += struct.pack("<2Qq", g.data_ptr(), flat.data_ptr() + 4 * off, g.numel())
+                chunks.extend((i, c) for c in range((g.numel() + chunk - 1) // chunk))
+                off += g.numel()
+            t_dev = torch.frombuffer(rec, dtype=torch.uint8).clone().to(flat.device)
+            c_dev = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(flat.device)
+            tab = (t_dev, c_dev, len(chunks))
+            if len(self._copy_tables) > 4 * max(len(self.buckets), 1):
+                self._copy_tables.clear()
+            self._copy_tables[key] = tab
+        return tab
+
+    def _pack(self, b, flat, grads):
+        # one table-driven launch per bucket (csrc/parallel.hip) instead of one copy per gradient (~140 tensors per network)
+        if flat.is_cuda and all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+            from ._lib import check, lib
+            t_dev, c_dev, n_chunks = self._copy_table(b, flat, grads)
+            check(lib().locate_multi_copy(t_dev.data_ptr(), c_dev.data_ptr(), n_chunks, 0, 1.0,
+                                          torch.cuda.current_stream(flat.device).cuda_stream), "locate_multi_copy")
+            return
+        torch._foreach_copy_(self._views(flat, grads), [g if g.is_contiguous() else g.contiguous() for g in grads])
 
     def finish(self):
         """Call after backward(), before optimizer.step(): afterwards every .grad holds the rank mean."""
-        if self.world == 1:
+        if not self.enabled:
             return
         self._active = False
         for b in range(len(self.buckets)):
@@ -222,7 +282,7 @@ class GradAllReducer:
             if dev.type == "cuda":
                 with torch.cuda.stream(self._side):
                     work.wait()
-                    self._unpack(flat, members, inv)
+                    self._unpack(b, flat, members, inv)
                     if self.timing:
                         ev = torch.cuda.Event(enable_timing=True)
                         ev.record(self._side)
@@ -232,7 +292,7 @@ class GradAllReducer:
                                 break
             else:
                 work.wait()
-                self._unpack(flat, members, inv)
+                self._unpack(b, flat, members, inv)
         if self._side is not None:
             cur = torch.cuda.current_stream(self._side.device)
             if self.timing:
@@ -258,7 +318,7 @@ class GradAllReducer:
         """Non-overlapped form: average every existing .grad across the ranks right now, on the current stream.
         Used between two captured hipGraphs (backward graph -> all-reduce -> optimizer graph), where the hook-driven
         overlap is not available; at config 2 the payload is 47 / 56 MB, ~1 ms of a 25 ms step over xGMI."""
-        if self.world == 1:
+        if not self.enabled:
             return
         inv = None if self._avg else 1.0 / self.world
         for b, idxs in enumerate(self.buckets):
@@ -271,12 +331,19 @@ class GradAllReducer:
             if flat is None or flat.numel() != total or flat.device != grads[0].device:
                 flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
                 self._flat[b] = flat
-            self._pack(flat, grads)
+            self._check_agreement(b, members)
+            self._pack(b, flat, grads)
             dist.all_reduce(flat, op=self._op(), group=self.group)
-            self._unpack(flat, members, inv)
+            self._unpack(b, flat, members, inv)
 
-    def _unpack(self, flat, members, inv):
+    def _unpack(self, b, flat, members, inv):
         grads = [self.params[i].grad for i in members]
+        if flat.is_cuda and all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+            from ._lib import check, lib
+            t_dev, c_dev, n_chunks = self._copy_table(b, flat, grads)
+            check(lib().locate_multi_copy(t_dev.data_ptr(), c_dev.data_ptr(), n_chunks, 1, 1.0 if inv is None else float(inv),
+                                          torch.cuda.current_stream(flat.device).cuda_stream), "locate_multi_copy")
+            return
         if inv is not None:
             flat.mul_(inv)
         if all(g.is_contiguous() for g in grads):

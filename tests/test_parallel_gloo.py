@@ -112,3 +112,79 @@ def test_single_process_is_a_no_op():
     (p * 2).sum().backward()
     red.finish()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def _worker_modes(rank, world, port, mode, q):
+    """mode "avg": the averaging-collective bookkeeping (no 1/world scaling on unpack: what RCCL's ReduceOp.AVG takes) pinned
+    over gloo, whose collectives cannot average - the reduction is a sum of inputs pre-scaled by 1/world, so the mean must
+    come out of the `inv is None` path.  mode "disagree": rank 1 lacks one gradient - both ranks must raise, not hang.
+    mode "force1": see test_forced_single_rank_runs_the_exchange."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from locate_amd.parallel import GradAllReducer
+        torch.manual_seed(3)
+        params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3)]
+        if mode == "avg":
+            red = GradAllReducer(params, bucket_bytes=32, reduce_op="avg")
+            red._op = lambda: dist.ReduceOp.SUM            # gloo has no AVG: sum of pre-scaled inputs instead
+            assert red._avg
+            for i, p in enumerate(params):
+                p.grad = torch.full_like(p, float(rank + 1 + i)) / world        # pre-scaled
+            red.begin()
+            red.finish()
+            ok = all(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 + i)) for i, p in enumerate(params))
+            red.reduce_now()                                                   # the same values averaged again: sum of x / ... stays put
+            q.put((rank, ok, ""))
+        elif mode == "disagree":
+            red = GradAllReducer(params, bucket_bytes=1 << 20)
+            for i, p in enumerate(params):
+                p.grad = None if (rank == 1 and i == 1) else torch.ones_like(p)
+            red.begin()
+            try:
+                red.finish()
+                q.put((rank, False, "no error raised"))
+            except RuntimeError as e:
+                q.put((rank, "disagree" in str(e), str(e)))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("mode", ["avg", "disagree"])
+def test_reducer_modes_world2(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_modes, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, (rank, info)
+
+
+def test_forced_single_rank_runs_the_exchange():
+    """force=True: a lone rank still packs, all-reduces (a self-copy) and unpacks - the one-rank rehearsal of the RCCL path
+    (`LOCATE_DP_FORCE=1 python -m torch.distributed.run --nproc-per-node 1 bench.py`)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from locate_amd.parallel import GradAllReducer
+        params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7)]
+        red = GradAllReducer(params, bucket_bytes=16, force=True)
+        assert red.enabled and len(red.buckets) == 2
+        red.begin()
+        sum((p * (i + 2)).sum() for i, p in enumerate(params)).backward()
+        assert all(red._launched)                      # both buckets went out from the post-accumulate hooks
+        red.finish()
+        assert all(torch.equal(p.grad, torch.full_like(p, float(i + 2))) for i, p in enumerate(params))
+        lone = GradAllReducer(params)
+        assert not lone.enabled
+    finally:
+        dist.destroy_process_group()
