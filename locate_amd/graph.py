@@ -92,7 +92,6 @@ class GraphedTrainStep:
                     self.sn_graph = torch.cuda.CUDAGraph()
                     with graph_ctx(self.sn_graph, self.pool_b):
                         step.dis.prefetch_spectral_norm(3)
-                    self._keep.extend(step.dis._sn_queue)
                 if step.d_cut is not None:
                     # data parallel: the D-step's backward as two graphs; replay() launches the deep segment's all-reduce
                     # between them, so that it runs beside the second segment

@@ -21,13 +21,22 @@ def discriminator_features(cfg):
 class SpectralNormBatch:
     """All SpectralNorm layers of one network advanced by four launches (blockIdx.y = layer) at the start of a
     forward instead of four launches per layer.  Equivalent to the reference's per-layer update because W_bar, u
-    and v of a layer only change at optimizer steps and every wrapped layer runs exactly once per model forward."""
+    and v of a layer only change at optimizer steps and every wrapped layer runs exactly once per model forward.
+
+    Every iteration's results - sigma, 1/sigma per layer and W v - are kept until the backward of the forward that used them,
+    so they go into a RING of `RING` result sets (one device table per set: the kernels write a set directly, nothing is
+    copied), handed out in order.  A forward over k stacked calls takes k CONSECUTIVE sets and reads them as one strided
+    view.  A set is overwritten RING iterations later; the backward of a forward whose set has been overwritten in the
+    meantime raises (`check`), it never reads another iteration's sigma."""
+    RING = 8
 
     def __init__(self, model):
         self.layers = [m for m in model.modules() if isinstance(m, SpectralNorm)]
         self._key = None
-        self._table = None
+        self._tables = None
         self._meta = None
+        self._next = 0
+        self._gen = [0] * self.RING
 
     def _build(self, device):
         import struct
@@ -49,50 +58,83 @@ class SpectralNormBatch:
         self._rec = rec
         self._struct = struct.Struct("<8Q4i")
 
-    def run(self):
-        """One power iteration for every layer (u, v advanced in place); returns this iteration's (sigma, wv)."""
-        from ._lib import check, lib
-        if not self.layers:
-            return None, None
-        dev = self.layers[0].module.weight_bar.device
-        if self._meta is None:
-            self._build(dev)
+    def _ensure_tables(self, dev):
         n = len(self.layers)
         key = tuple((sn.module.weight_bar.data_ptr(), sn.module.weight_u.data_ptr(), sn.module.weight_v.data_ptr())
                     for sn in self.layers)
-        if key != self._key:
-            # persistent output buffers: the kernels write here, every forward takes its own copy below
-            tot_h = sum(h for h, _, _ in self._meta)
-            self._sig = torch.empty(n, 2, dtype=torch.float32, device=dev)
-            self._wvs = torch.empty(tot_h, dtype=torch.float32, device=dev)
+        if key == self._key:
+            return
+        tot_h = sum(h for h, _, _ in self._meta)
+        self._sig = torch.empty(self.RING, n, 2, dtype=torch.float32, device=dev)
+        self._wvs = torch.empty(self.RING, tot_h, dtype=torch.float32, device=dev)
+        self._tables = []
+        base = self._scratch.data_ptr()
+        for r in range(self.RING):
             buf = bytearray()
             off, hoff = 0, 0
-            base = self._scratch.data_ptr()
             for i, (sn, (h, wd, nch)) in enumerate(zip(self.layers, self._meta)):
                 m = sn.module
                 t = base + 4 * off
                 s = t + 4 * wd
                 tp = s + 4 * h
                 buf += self._struct.pack(m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(),
-                                         self._sig.data_ptr() + 8 * i, self._wvs.data_ptr() + 4 * hoff, t, s, tp, h, wd, nch, 0)
+                                         self._sig[r].data_ptr() + 8 * i, self._wvs[r].data_ptr() + 4 * hoff, t, s, tp, h, wd, nch, 0)
                 off += wd + h + nch * wd
                 hoff += h
             host = torch.frombuffer(buf, dtype=torch.uint8)
-            self._table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
-            self._table.copy_(host)
-            self._key = key
-        check(lib().locate_sn_power_iter_batched(self._table.data_ptr(), n, self.max_h, self.max_wd,
-                                                 torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
-        sig, wvs = self._sig.clone(), self._wvs.clone()   # this forward's sigma / W v (kept for its backward)
-        return sig, wvs
+            table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+            table.copy_(host)
+            self._tables.append(table)
+        self._key = key
 
-    def assign(self, sig, wvs):
-        """Hand one power iteration's results to the layers (consumed by their next forward).  sig [n, 2], wvs [H]; or,
-        for a forward over k stacked calls, sig [n, k, 2], wvs [k, H] (one iteration per call, in call order)."""
+    def run(self, count=1):
+        """`count` power iterations for every layer, one after the other (u, v advanced in place), into `count` consecutive
+        result sets; returns the list of their ring positions [(set, generation)]."""
+        from ._lib import check, lib
+        if not self.layers:
+            return None
+        dev = self.layers[0].module.weight_bar.device
+        if self._meta is None:
+            self._build(dev)
+        self._ensure_tables(dev)
+        if count > self.RING:
+            raise ValueError("at most %d stacked calls" % self.RING)
+        if self._next + count > self.RING:
+            self._next = 0                       # k stacked calls read their sets as ONE strided view: no wrap-around inside
+        out = []
+        for _ in range(count):
+            r = self._next
+            self._next = (r + 1) % self.RING
+            self._gen[r] += 1
+            check(lib().locate_sn_power_iter_batched(self._tables[r].data_ptr(), len(self.layers), self.max_h, self.max_wd,
+                                                     torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
+            out.append((r, self._gen[r]))
+        return out
+
+    def check(self, sets):
+        """Raises if any of the result sets [(set, generation)] has been overwritten by a later iteration."""
+        for r, gen in sets:
+            if self._gen[r] != gen:
+                raise RuntimeError("spectral norm: the sigma of this forward was overwritten - more than %d forwards of the "
+                                   "network ran before its backward (SpectralNormBatch.RING)" % self.RING)
+
+    def assign(self, sets):
+        """Hand the results of one iteration - or of k iterations for a forward over k stacked calls, in call order - to the
+        layers (consumed by their next forward): per layer (sigma [2], wv [h]), resp. (sigma [k, 2], wv [k, h])."""
         hoff = 0
-        stacked = sig.dim() == 3
+        k = len(sets)
+        first = sets[0][0]
+        consecutive = all(sets[j][0] == first + j for j in range(k))
+        if k == 1:
+            sig, wvs = self._sig[first], self._wvs[first]
+        elif consecutive:
+            sig, wvs = self._sig[first:first + k].permute(1, 0, 2), self._wvs[first:first + k]          # views: [n, k, 2], [k, H]
+        else:
+            idx = [r for r, _ in sets]
+            sig, wvs = self._sig[idx].permute(1, 0, 2).contiguous(), self._wvs[idx]
+        guard = (self, tuple(sets))
         for i, (sn, (h, _, _)) in enumerate(zip(self.layers, self._meta)):
-            sn._pre = (sig[i], wvs[:, hoff:hoff + h] if stacked else wvs[hoff:hoff + h])
+            sn._pre = (sig[i], wvs[:, hoff:hoff + h] if k > 1 else wvs[hoff:hoff + h], guard)
             hoff += h
 
 
@@ -124,11 +166,9 @@ class _NetBase(nn.Module):
         """Run the power iterations of the next `n_forwards` forwards now, in order, on the current stream.  The
         forwards themselves may then run concurrently on different streams: each consumes one queued result, exactly
         the (u, v, sigma) sequence the reference produces by iterating at the start of every forward."""
-        b = self._batch()
-        for _ in range(n_forwards):
-            sig, wvs = b.run()
-            if sig is not None:
-                self._sn_queue.append((sig, wvs))
+        sets = self._batch().run(n_forwards)
+        if sets is not None:
+            self._sn_queue.extend(sets)
 
     def _sn_prologue(self, stacked=1):
         ops.AMAX.new_pass()          # this forward's largest-magnitude words come from a block of their own
@@ -136,13 +176,12 @@ class _NetBase(nn.Module):
             raise RuntimeError("a forward over stacked calls needs batched_spectral_norm = True")
         if self.batched_spectral_norm:
             b = self._batch()
-            runs = [self._sn_queue.pop(0) if self._sn_queue else b.run() for _ in range(stacked)]
-            if runs[0][0] is None:
+            if not b.layers:
                 return
-            if stacked == 1:
-                b.assign(*runs[0])
-            else:
-                b.assign(torch.stack([r[0] for r in runs], dim=1), torch.stack([r[1] for r in runs], dim=0))
+            sets = [self._sn_queue.pop(0) for _ in range(min(stacked, len(self._sn_queue)))]
+            if len(sets) < stacked:
+                sets += b.run(stacked - len(sets))
+            b.assign(sets)
 
 
 class Generator(_NetBase):

@@ -151,17 +151,19 @@ class SpectralNorm(_Bound):
         raise NotImplementedError("SpectralNorm over %s" % type(m).__name__)
 
     def take_pre(self):
-        """(sigma, wv) of this forward's power iteration: left by a batched update, or run now."""
+        """(sigma, wv, guard) of this forward's power iteration: left by a batched update (guard: its ring sets, checked at
+        backward time), or run now (guard None)."""
         m = self.module
         pre, self._pre = self._pre, None
         if pre is None:
             pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
-        return pre
+        return tuple(pre) + (None,) * (3 - len(pre))
 
     def forward(self, x):
         m = self.module
         x4, w4, spec, restore = self._plan(x)
-        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, self.take_pre(), self.runtime)
+        sigma, wv, guard = self.take_pre()
+        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard)
         return restore(y)
 
 

@@ -1128,7 +1128,8 @@ class SNConvFn(torch.autograd.Function):
     left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None):
+        ctx.guard = guard              # (SpectralNormBatch, its ring sets): sigma / wv are views of them, still intact at backward?
         x = _dense(x, "conv input")
         w = _c(w_bar, "weight_bar")
         owner = _panel_owner(w_bar)
@@ -1158,6 +1159,8 @@ class SNConvFn(torch.autograd.Function):
             x, w, sigma, wv = ctx.saved_tensors
             y = bsaved = None
         spec, garr = ctx.spec, _geom(ctx.geom)
+        if ctx.guard is not None:
+            ctx.guard[0].check(ctx.guard[1])
         gy = _dense(gy, "conv output gradient")
         amax_gy = _amax_of(gy)
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
@@ -1189,13 +1192,13 @@ class SNConvFn(torch.autograd.Function):
         if ctx.has_bias and need_b:
             gb = _bias_grad(gy)
         # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None, None
+        return gx, gw, gu, None, gb, None, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
-    batched update is supplied."""
+    batched update is supplied (guard: see SNConvFn.forward)."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard)
