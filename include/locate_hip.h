@@ -233,6 +233,10 @@ int locate_fin_sn_dot_partials(int Bg, int M, int plane);
 int locate_fin_sn_dots(const void* records, int n, void* stream);
 int locate_fin_sn_rank1(const void* records, int n, void* stream);
 int locate_fin_sums(const void* records, int n, void* stream);
+/* channel sums out[c] = sum_{b,hw} g[b,c,hw] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) for all biases of a pass:
+ * records p = {g, out [C], partials [slices][C] | 0}, l = {batch stride}, i = {B, C, hw}; slices = locate_fin_channel_slices */
+int locate_fin_channel_slices(int B, int C, int hw);
+int locate_fin_channel_sums(const void* records, int n, void* stream);
 
 /* ---- gradient bucket pack / unpack of the data-parallel exchange (no reference counterpart: libs/config.py:10-11 is single
  *      device).  tensors: DEVICE array of {float* grad; float* flat; int64 n} records (locate_multi_copy_record_bytes() = 24);

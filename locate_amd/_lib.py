@@ -91,6 +91,8 @@ PROTOTYPES = {
     "locate_fin_sn_dots": (c_i, [c_p, c_i, c_p]),
     "locate_fin_sn_rank1": (c_i, [c_p, c_i, c_p]),
     "locate_fin_sums": (c_i, [c_p, c_i, c_p]),
+    "locate_fin_channel_slices": (c_i, [c_i, c_i, c_i]),
+    "locate_fin_channel_sums": (c_i, [c_p, c_i, c_p]),
     "locate_gate_bwd_partials": (c_i, [c_i64, c_i]),
     "locate_multi_copy_record_bytes": (c_sz, []),
     "locate_multi_copy_chunk_elems": (c_i, []),

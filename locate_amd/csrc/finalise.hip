@@ -143,6 +143,62 @@ __global__ void __launch_bounds__(256) fin_sums_kernel(const FinBatch batch) {
     if (threadIdx.x == 0) static_cast<float*>(const_cast<void*>(R.p[1]))[0] = (float)acc;
 }
 
+// ---- per-channel sums over batch and space (the bias gradients of the 1x1 skip convs and of the style linears) ---------
+// The arithmetic of norm.hip's channel_sum_kernel / channel_sum_final_kernel (same thread-to-element map, same order), for all
+// biases of a backward pass in two launches: blocks of 1024 threads over (channel, batch slice) pairs of every record, then one
+// block per record adding its slices.
+// p0 g, p1 out [C], p2 slice partials [slices][C] (unused when slices = 1);  l0 batch stride;  i0 B, i1 C, i2 hw, i3 slices,
+// i4 batch elements per slice, i5 first block of this record in the launch, i6 its block count (= C * slices)
+__global__ void __launch_bounds__(1024) fin_channel_sums_kernel(const FinBatch batch, int n_rec) {
+    __shared__ float scratch[16];
+    int ri = 0;
+    for (int k = 1; k < n_rec; ++k)
+        if ((int)blockIdx.x >= batch.r[k].i[5]) ri = k;
+    const FinRec& R = batch.r[ri];
+    const int bx = (int)blockIdx.x - R.i[5];
+    const int B = R.i[0], C = R.i[1], hw = R.i[2], slices = R.i[3], per_slice = R.i[4];
+    const int c = bx % C, sl = bx / C;
+    const float* __restrict__ g = static_cast<const float*>(R.p[0]);
+    float* __restrict__ out = static_cast<float*>(const_cast<void*>(slices > 1 ? R.p[2] : R.p[1]));
+    const int64_t batch_stride = R.l[0];
+    const int b0 = sl * per_slice;
+    const int nb = min(per_slice, B - b0);
+    float acc = 0.0f;
+    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (nb > 0) {
+        if (vec) {
+            const int hw4 = hw >> 2;
+            const int total = nb * hw4;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int b = i / hw4, r = i - b * hw4;
+                const float4 v = reinterpret_cast<const float4*>(g + (int64_t)(b0 + b) * batch_stride + (int64_t)c * hw)[r];
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            const int total = nb * hw;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int b = i / hw, r = i - b * hw;
+                acc += g[(int64_t)(b0 + b) * batch_stride + (int64_t)c * hw + r];
+            }
+        }
+    }
+    acc = block_sum<float>(acc, scratch);
+    if (threadIdx.x == 0) out[(int64_t)sl * C + c] = acc;
+}
+
+__global__ void __launch_bounds__(256) fin_channel_final_kernel(const FinBatch batch) {
+    const FinRec& R = batch.r[blockIdx.x];
+    const int C = R.i[1], slices = R.i[3];
+    if (slices <= 1) return;
+    const float* __restrict__ part = static_cast<const float*>(R.p[2]);
+    float* __restrict__ out = static_cast<float*>(const_cast<void*>(R.p[1]));
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int s = 0; s < slices; ++s) acc += part[(int64_t)s * C + c];
+        out[c] = acc;
+    }
+}
+
 // number of partial sums per stacked call that locate_fin_sn_dots writes for a layer output of Bg x M x plane per call
 LOCATE_API int locate_fin_sn_dot_partials(int Bg, int M, int plane) {
     const int64_t work = (int64_t)Bg * (((int64_t)M * plane + FIN_DOT_CHUNK - 1) / FIN_DOT_CHUNK);
@@ -190,6 +246,47 @@ LOCATE_API int locate_fin_sn_rank1(const void* records, int n, void* stream) {
         }
         fin_sn_rank1_kernel<<<blocks, 256, 0, as_stream(stream)>>>(b, m);
         LOCATE_LAUNCH_CHECK("locate_fin_sn_rank1");
+    }
+    return LOCATE_OK;
+}
+
+// slices of the batch a channel sum of [B, C, hw] is split into (so that few channels still fill the chip) - the rule of
+// locate_channel_sum; the record's partial buffer p2 needs slices * C floats when this is > 1
+LOCATE_API int locate_fin_channel_slices(int B, int C, int hw) {
+    if (C >= 512 || (int64_t)B * hw < 8192) return 1;
+    int s = (1024 + C - 1) / C;
+    if (s > B) s = B;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+LOCATE_API int locate_fin_channel_sums(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0, "locate_fin_channel_sums: bad arguments");
+    const FinRec* rec = static_cast<const FinRec*>(records);
+    for (int at = 0; at < n; at += FIN_MAX) {
+        FinBatch b = {};
+        const int m = n - at < FIN_MAX ? n - at : FIN_MAX;
+        int blocks = 0;
+        bool any_split = false;
+        for (int k = 0; k < m; ++k) {
+            b.r[k] = rec[at + k];
+            FinRec& R = b.r[k];
+            LOCATE_REQUIRE(R.p[0] && R.p[1] && R.i[0] > 0 && R.i[1] > 0 && R.i[2] > 0, "locate_fin_channel_sums: bad record %d", at + k);
+            const int slices = locate_fin_channel_slices(R.i[0], R.i[1], R.i[2]);
+            LOCATE_REQUIRE(slices == 1 || R.p[2], "locate_fin_channel_sums: record %d needs a partial buffer", at + k);
+            R.i[3] = slices;
+            R.i[4] = (R.i[0] + slices - 1) / slices;
+            R.i[5] = blocks;
+            R.i[6] = R.i[1] * slices;
+            blocks += R.i[6];
+            any_split = any_split || slices > 1;
+        }
+        fin_channel_sums_kernel<<<blocks, 1024, 0, as_stream(stream)>>>(b, m);
+        LOCATE_LAUNCH_CHECK("locate_fin_channel_sums");
+        if (any_split) {
+            fin_channel_final_kernel<<<m, 256, 0, as_stream(stream)>>>(b);
+            LOCATE_LAUNCH_CHECK("locate_fin_channel_sums(final)");
+        }
     }
     return LOCATE_OK;
 }

@@ -159,11 +159,13 @@ class SpectralNorm(_Bound):
             pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
         return tuple(pre) + (None,) * (3 - len(pre))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out (Conv2d / ConvTranspose2d only): a channel slice of a concatenation buffer to write the result into."""
         m = self.module
         x4, w4, spec, restore = self._plan(x)
         sigma, wv, guard = self.take_pre()
-        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard)
+        y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard,
+                        out if restore is _identity else None)
         return restore(y)
 
 
@@ -188,9 +190,20 @@ class _TwoBranch(nn.Module):
 
 
 class CatModule(_TwoBranch):
-    """Channel concatenation [skip, layer] (libs/merge.py:4-16)."""
+    """Channel concatenation [skip, layer] (libs/merge.py:4-16).  Where the layer is a spectral-normalised conv on the same
+    input (every use in the two networks: libs/scale.py:28-34) it writes its result straight into its slice of the
+    concatenation, and only the skip part is copied."""
 
     def forward(self, function_input, layer_input=None, scale=None):
+        layer = self.layer_module
+        if (layer_input is None and scale is None and self.residual_module is _identity and isinstance(layer, SpectralNorm)
+                and isinstance(layer.module, nn.Conv2d) and function_input.dim() == 4 and function_input.is_cuda):
+            m = layer.module
+            x = function_input
+            if (m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.groups == 1 and x.shape[1] == m.in_channels):
+                buf = x.new_empty((x.shape[0], x.shape[1] + m.out_channels) + tuple(x.shape[2:]))
+                branch = layer(x, out=buf[:, x.shape[1]:])
+                return ops.cat_channels(x, branch, [buf])
         return ops.cat_channels(*self._run(function_input, layer_input, scale))
 
 

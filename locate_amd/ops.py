@@ -216,6 +216,8 @@ class Runtime:
         self._fin_dots = []              # packed FinRec records (csrc/finalise.hip)
         self._fin_rank1 = []
         self._fin_sums = []
+        self._fin_chan = []
+        self._streams = {}               # streams on which this pass queued deferred work / produced late gradients
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
     def __deepcopy__(self, memo):
@@ -240,14 +242,20 @@ class Runtime:
         self._side = None
         self._side_results = []
         self._keep = []
+        self._streams = {}
         AMAX.new_pass()
-        self._fin_dots, self._fin_rank1, self._fin_sums = [], [], []
+        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan = [], [], [], []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
         self._dv_layers = {}
 
     # ---- end-of-backward work ----------------------------------------------------------------------------------------
     def _schedule_end(self):
+        # whatever is finished at the end of the pass must first be complete on the stream it was produced on: the backward
+        # nodes of a multi-stream forward (three-stream D-step) run on their forward's streams, and a layer whose gradients are
+        # all deferred leaves no AccumulateGrad on its stream for the engine's own end-of-pass join to find
+        st = torch.cuda.current_stream()
+        self._streams[st.cuda_stream] = st
         if not self._end_scheduled:
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             self._end_scheduled = True
@@ -255,19 +263,25 @@ class Runtime:
     def _end_of_backward(self):
         self._end_scheduled = False
         side, self._side = self._side, None
+        cur = torch.cuda.current_stream()
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            cur.wait_stream(side)
+        used, self._streams = self._streams, {}
+        for sid, st_ in used.items():
+            if sid != cur.cuda_stream:
+                cur.wait_stream(st_)
         # the queued finalisers, one launch per kind for the whole pass; the rank-1 launch also fills the dsigma slots the
         # batched dv below reads
         L = lib()
         st = _stream()
         for queue, fn, name in ((self._fin_dots, L.locate_fin_sn_dots, "locate_fin_sn_dots"),
                                 (self._fin_rank1, L.locate_fin_sn_rank1, "locate_fin_sn_rank1"),
-                                (self._fin_sums, L.locate_fin_sums, "locate_fin_sums")):
+                                (self._fin_sums, L.locate_fin_sums, "locate_fin_sums"),
+                                (self._fin_chan, L.locate_fin_channel_sums, "locate_fin_channel_sums")):
             if queue:
                 blob = b"".join(queue)
                 check(fn(blob, len(queue), st), name)
-        self._fin_dots, self._fin_rank1, self._fin_sums = [], [], []
+        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan = [], [], [], []
         results, self._side_results = self._side_results, []
         self._keep = []
         for param, grad in results:
@@ -297,6 +311,16 @@ class Runtime:
     def queue_sum(self, partial, count, out):
         self._fin_sums.append(self._rec([partial, out], [], [count]))
         self._keep.append((partial, out))
+        self._schedule_end()
+
+    def queue_channel_sum(self, g, out):
+        """out[c] = sum over batch and space of g[:, c] (a bias gradient), with the pass's other channel sums."""
+        Bn, Cn = g.shape[0], g.shape[1]
+        hw = g.numel() // (Bn * Cn)
+        slices = lib().locate_fin_channel_slices(Bn, Cn, hw)
+        part = torch.empty(slices * Cn, dtype=torch.float32, device=g.device) if slices > 1 else None
+        self._fin_chan.append(self._rec([g, out, part], [g.stride(0)], [Bn, Cn, hw]))
+        self._keep.append((g, out, part))
         self._schedule_end()
 
     def late_grad(self, param, grad):
@@ -760,15 +784,22 @@ def _dense_planes(t):
 
 
 class CatChannelsFn(torch.autograd.Function):
-    """torch.cat([a, b], dim=1) (libs/merge.py:15) as two strided plane copies."""
+    """torch.cat([a, b], dim=1) (libs/merge.py:15) as two strided plane copies - or one: when b was WRITTEN by its producer
+    straight into the channel slice of `buf` that the concatenation assigns to it (cat_buffer / sn_conv(out=...)), only a is
+    copied."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        a, b = _c(a, "cat input"), _c(b, "cat input")
+    def forward(ctx, a, b, holder=None):
+        a = _c(a, "cat input")
         ca, cb = a.shape[1], b.shape[1]
-        out = torch.empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+        buf = holder[0] if holder else None
+        if buf is not None and buf.shape[1] == ca + cb and b.data_ptr() == buf[:, ca:].data_ptr() and b.stride() == buf[:, ca:].stride():
+            out = buf
+        else:
+            b = _c(b, "cat input")
+            out = torch.empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+            _copy_channels(b, out[:, ca:])
         _copy_channels(a, out[:, :ca])
-        _copy_channels(b, out[:, ca:])
         ctx.split = (ca, cb)
         return out
 
@@ -777,10 +808,11 @@ class CatChannelsFn(torch.autograd.Function):
         # channel slices of the incoming gradient, as views: the conv kernels consume batch-strided operands in place,
         # everything else copies only if it has to
         ca, cb = ctx.split
-        return g[:, :ca], g[:, ca:]
+        return g[:, :ca], g[:, ca:], None
 
 
-cat_channels = CatChannelsFn.apply
+def cat_channels(a, b, holder=None):
+    return CatChannelsFn.apply(a, b, holder)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1013,9 +1045,13 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
     return y
 
 
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0, amax=None):
-    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`)."""
-    y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0, amax=None, out=None):
+    """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`).  out: a dense-plane view of that
+    shape to write into (a channel slice of a concatenation buffer) instead of a fresh tensor."""
+    if out is not None and spec.mode == "dense" and tuple(out.shape) == tuple(out_shape) and _dense_planes(out) and out.dtype == torch.float32:
+        y = out
+    else:
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
     return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision, amax)
 
 
@@ -1128,7 +1164,9 @@ class SNConvFn(torch.autograd.Function):
     left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None, out_holder=None):
+        # out_holder: [view] - the output is written into this channel slice of a concatenation buffer (hidden in a list so
+        # that autograd does not see an input being returned)
         ctx.guard = guard              # (SpectralNormBatch, its ring sets): sigma / wv are views of them, still intact at backward?
         x = _dense(x, "conv input")
         w = _c(w_bar, "weight_bar")
@@ -1138,7 +1176,7 @@ class SNConvFn(torch.autograd.Function):
         b = _c(bias) if bias is not None else None
         rt = rt or DEFAULT_RUNTIME
         ctx.amax_x = _amax_of(x)
-        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x)
+        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x, out_holder[0] if out_holder else None)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
         ctx.groups = groups
         if groups > 1:
@@ -1146,6 +1184,7 @@ class SNConvFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, w, sigma, wv)
         ctx.u, ctx.v = u, v            # live state, read at backward time
+        ctx.bias_param = bias
         ctx.owner = owner
         ctx.rt = rt
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
@@ -1190,15 +1229,20 @@ class SNConvFn(torch.autograd.Function):
             else:
                 gw, gu = (sgw if need_w else None), sgu
         if ctx.has_bias and need_b:
-            gb = _bias_grad(gy)
+            if ctx.rt.defer_finalisers and ctx.bias_param.is_leaf:
+                late_gb = torch.empty(gy.shape[1], dtype=torch.float32, device=gy.device)
+                ctx.rt.queue_channel_sum(gy, late_gb)
+                ctx.rt.late_grad(ctx.bias_param, late_gb.view(ctx.bias_param.shape))
+            else:
+                gb = _bias_grad(gy)
         # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None, None, None
+        return gx, gw, gu, None, gb, None, None, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None, out=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
-    batched update is supplied (guard: see SNConvFn.forward)."""
+    batched update is supplied (guard: see SNConvFn.forward).  out: view to write the result into (see _conv_apply)."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard, None if out is None else [out])
