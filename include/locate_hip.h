@@ -42,7 +42,9 @@ int locate_absmax(const float* x, int64_t n, void* absmax, void* stream);
 /* style chain link (libs/block.py:119-125): out[r, :z] = latent[r, :], out[r, z:] = RootTanh(pre[r, :]) in one launch, and
  * its backward on the gradient's column slice in place (row stride in elements) */
 int locate_act_cat_rows_fwd(const float* latent, const float* pre, float* out, int rows, int z, int w, void* stream);
-int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, float* gpre, int rows, int w, void* stream);
+/* g_add (nullable, [rows, w] contiguous): added to the result - the gradient pre receives as a norm's style scale */
+int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, const float* g_add, float* gpre, int rows, int w,
+                        void* stream);
 int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream);
 

@@ -30,7 +30,7 @@ PROTOTYPES = {
     "locate_roottanh_fwd": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "locate_act_cat_rows_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "locate_act_rows_bwd": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, c_p]),
+    "locate_act_rows_bwd": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_p]),
     "locate_absmax_words": (c_i, []),
     "locate_absmax": (c_i, [c_p, c_i64, c_p, c_p]),
     "locate_tanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),

@@ -111,13 +111,15 @@ __global__ void __launch_bounds__(256) act_cat_rows_kernel(const float* __restri
     }
 }
 
-// gpre[r, j] = g[r * g_rs + j] * RootTanh'(pre[r, j])
+// gpre[r, j] = g[r * g_rs + j] * RootTanh'(pre[r, j])  (+ g_add[r, j]: the gradient pre receives as a norm's style scale -
+// the sum autograd would otherwise form with a launch of its own; a separately rounded add, bit for bit the same sum)
 __global__ void __launch_bounds__(256) act_rows_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ g, int g_rs,
-                                                           float* __restrict__ gpre, int rows, int w) {
+                                                           const float* __restrict__ g_add, float* __restrict__ gpre, int rows, int w) {
     const int total = rows * w;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int r = i / w, j = i - r * w;
-        gpre[i] = roottanh_grad_f(pre[i], g[(int64_t)r * g_rs + j]);
+        const float v = roottanh_grad_f(pre[i], g[(int64_t)r * g_rs + j]);
+        gpre[i] = g_add ? __fadd_rn(g_add[i], v) : v;
     }
 }
 
@@ -128,9 +130,10 @@ LOCATE_API int locate_act_cat_rows_fwd(const float* latent, const float* pre, fl
     return LOCATE_OK;
 }
 
-LOCATE_API int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, float* gpre, int rows, int w, void* stream) {
+LOCATE_API int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, const float* g_add, float* gpre, int rows,
+                                   int w, void* stream) {
     LOCATE_REQUIRE(pre && g && gpre && rows > 0 && w > 0 && g_row_stride >= w && g_row_stride < (1ll << 31), "locate_act_rows_bwd: bad arguments");
-    act_rows_bwd_kernel<<<stream_grid((int64_t)rows * w, 256), 256, 0, as_stream(stream)>>>(pre, g, (int)g_row_stride, gpre, rows, w);
+    act_rows_bwd_kernel<<<stream_grid((int64_t)rows * w, 256), 256, 0, as_stream(stream)>>>(pre, g, (int)g_row_stride, g_add, gpre, rows, w);
     LOCATE_LAUNCH_CHECK("locate_act_rows_bwd");
     return LOCATE_OK;
 }

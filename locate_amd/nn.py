@@ -462,21 +462,38 @@ class BlockBlock(nn.Module):
 
     def _style_scales(self, stage, latent, carry):
         """Runs stage `stage`'s style linears: each sees [latent, previous activated output] and yields (a) its RootTanh
-        output - the next link's carry - and (b) its pre-activation as a [B, C, 1, 1] norm scale."""
+        output - the next link's carry - and (b) its pre-activation as a [B, C, 1, 1] norm scale.  The activation of link k and
+        its concatenation with the latent are one launch, issued when link k + 1 needs them; that launch's autograd node also
+        hands out link k's scale (ops.act_cat_scale), so the scales lag one link behind: `carry` = (pre of the last link,
+        position of its still missing scale)."""
         scales = []
         start = self.first_style[stage]
         for linear in self.mul_blocks[start:start + len(self.plan[stage].style)]:
-            # `carry` is the previous link's PRE-activation: RootTanh and the concatenation with the latent are one launch
-            pre = linear.pre_activation(latent if carry is None else ops.act_cat(latent, carry))
-            scales.append(pre.view(*pre.shape, 1, 1))
-            carry = pre
+            if carry is None:
+                inp = latent
+            else:
+                inp, prev_scale = ops.act_cat_scale(latent, carry[0])
+                carry[1][carry[2]] = prev_scale                  # the previous link's scale, now that its node exists
+            pre = linear.pre_activation(inp)
+            scales.append(None)
+            carry = (pre, scales, len(scales) - 1)
         return scales, carry
 
     def forward(self, function_input, noise=None):
         out, carry = function_input, None
-        for stage, block in enumerate(self.blocks):
-            scales = None
-            if noise is not None:
-                scales, carry = self._style_scales(stage, noise, carry)
+        if noise is None:
+            for block in self.blocks:
+                out = block(out, scales=None)
+            return out
+        # the whole style chain first (it depends on the latent alone): every link's scale comes out of the autograd node of
+        # the NEXT link's activation, the last link's is a plain view
+        per_stage = []
+        for stage in range(len(self.blocks)):
+            scales, carry = self._style_scales(stage, noise, carry)
+            per_stage.append(scales)
+        if carry is not None:
+            pre = carry[0]
+            carry[1][carry[2]] = pre.view(*pre.shape, 1, 1)
+        for block, scales in zip(self.blocks, per_stage):
             out = block(out, scales=scales)
         return out

@@ -145,7 +145,9 @@ class TanhFn(torch.autograd.Function):
 
 class ActCatFn(torch.autograd.Function):
     """cat([latent, RootTanh(pre)], dim=1) for [B, z] / [B, w] matrices in ONE launch - a style-chain link
-    (libs/block.py:119-125: the next style linear sees the latent next to the previous link's activated output)."""
+    (libs/block.py:119-125: the next style linear sees the latent next to the previous link's activated output).
+    Second output: pre itself as the [B, w, 1, 1] norm scale it also is (libs/block.py:124) - so that pre has ONE consumer and
+    its two gradients (through the activation, and as a scale) meet inside one backward kernel instead of an autograd add."""
 
     @staticmethod
     def forward(ctx, latent, pre):
@@ -156,18 +158,21 @@ class ActCatFn(torch.autograd.Function):
         check(lib().locate_act_cat_rows_fwd(_p(latent), _p(pre), _p(out), rows, z, w, _stream()), "locate_act_cat_rows_fwd")
         ctx.save_for_backward(pre)
         ctx.z = z
-        return out
+        return out, pre.view(rows, w, 1, 1)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_scale):
         pre, = ctx.saved_tensors
+        z = ctx.z
+        if g is None:
+            return None, (None if g_scale is None else g_scale.reshape(pre.shape))
         g = _chk(g, "style chain gradient")
         if g.stride(1) != 1:
             g = g.contiguous()
-        z = ctx.z
+        add = None if g_scale is None else _c(g_scale, "style scale gradient")
         gpre = torch.empty_like(pre)
-        check(lib().locate_act_rows_bwd(_p(pre), g.data_ptr() + 4 * z, g.stride(0), _p(gpre), pre.shape[0], pre.shape[1], _stream()),
-              "locate_act_rows_bwd")
+        check(lib().locate_act_rows_bwd(_p(pre), g.data_ptr() + 4 * z, g.stride(0), _p(add), _p(gpre), pre.shape[0], pre.shape[1],
+                                        _stream()), "locate_act_rows_bwd")
         return (g[:, :z] if ctx.needs_input_grad[0] else None), gpre
 
 
@@ -180,7 +185,16 @@ def root_tanh(x):
         y._locate_amax = amax
     return y
 tanh = TanhFn.apply
-act_cat = ActCatFn.apply
+
+
+def act_cat(latent, pre):
+    """cat([latent, RootTanh(pre)], 1) alone (see act_cat_scale)."""
+    return ActCatFn.apply(latent, pre)[0]
+
+
+def act_cat_scale(latent, pre):
+    """(cat([latent, RootTanh(pre)], 1), pre as a [B, w, 1, 1] style scale) - use the returned scale INSTEAD of viewing pre."""
+    return ActCatFn.apply(latent, pre)
 
 
 # ------------------------------------------------------------------------------------------------
