@@ -163,7 +163,12 @@ size_t locate_conv_counter_bytes(void);
  * configs[1] names; tolerance against the fp32 path stated in tests/test_gpu_bf16.py. */
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                     int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
-                    void* counters, int precision, const void* x_absmax, void* stream);
+                    void* counters, int precision, const void* x_absmax, const void* act_epilogue, void* stream);
+/* act_epilogue (nullable; layers on 1x1 maps only - style linears, the channel gate's squeeze convs): HOST pointer to
+ *   struct { void* act_out; int64_t act_bs; const void* lat; int64_t lat_bs; int32_t lat_z, pad; }
+ * the launch also writes act_out[n * act_bs + j] = RootTanh(y[n, j]) (libs/linear.py:12-13, libs/attention.py:26,31) and, with
+ * lat, copies lat[n, 0 .. lat_z) in front of it (act_out[n * act_bs - lat_z ..]): the next style link's input
+ * cat([latent, activated]) (libs/block.py:119-125) in the same launch */
 /* precision: 0 = fp32-faithful with three bf16 pieces per operand (six bf16 MFMAs per 32x32x16 slice); 1 = operands rounded
  * to bf16 (one MFMA); 2 = fp32-faithful with TWO fp16 pieces per operand (three fp16 MFMAs): both operands are scaled by a
  * power of two into fp16's range - the weights when the panel is packed (panel format bit: `adjoint | 2` in

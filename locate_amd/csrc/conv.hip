@@ -458,6 +458,14 @@ struct IgParams {
     int precision;       // 0: fp32-faithful (three bf16 pieces per operand, six MFMAs per slice); 1: bf16 operands (one piece);
                          // 2: fp32-faithful with two scaled fp16 pieces per operand, three MFMAs per slice (panel format 1)
     const unsigned* b_absmax;   // precision 2: largest magnitude of the gathered tensor as AMAX_WORDS words of bit patterns (common.h)
+    // activated second output (1x1-map layers, skinny_rows_kernel only): act_out[n, j] = RootTanh(out[n, j]) with its own row
+    // stride, and - a style-chain link writing the NEXT link's input [latent | activation] (libs/block.py:119-125) - the
+    // lat_z latent columns copied in front of it: act_out - lat_z is then the start of that row
+    float* act_out;
+    long long act_bs;
+    const float* lat;
+    long long lat_bs;
+    int lat_z;
     int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
     unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
     IgPhase ph[4];
@@ -1279,8 +1287,12 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_rows_kernel(const IgPara
 #pragma unroll
             for (int w = 1; w < SK_WAVES; ++w) s += red[w][wid][lane];
             const float sc = p.scale ? p.scale[(p.scale_bg ? n / p.scale_bg : 0) * p.scale_stride] : 1.0f;
-            p.out[(long long)n * p.out_bs + j] = fmaf(s, sc, p.bias ? p.bias[j] : 0.0f);
+            const float v = fmaf(s, sc, p.bias ? p.bias[j] : 0.0f);
+            p.out[(long long)n * p.out_bs + j] = v;
+            if (p.act_out) p.act_out[(long long)n * p.act_bs + j] = roottanh_f(v);
         }
+        if (p.lat && blockIdx.x == 0 && n < N)          // the latent columns of the next link's input row n
+            for (int c = lane; c < p.lat_z; c += 64) p.act_out[(long long)n * p.act_bs - p.lat_z + c] = p.lat[(long long)n * p.lat_bs + c];
     }
 }
 
@@ -1690,14 +1702,24 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
     return LOCATE_OK;
 }
 
+// optional activated second output of locate_conv_fwd (HOST struct, see IgParams::act_out)
+struct LocateActEpilogue {
+    void* act_out;
+    long long act_bs;
+    const void* lat;
+    long long lat_bs;
+    int lat_z, pad;
+};
+
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
                      int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, unsigned* counters,
-                     int precision, const unsigned* in_absmax, hipStream_t st, const char* who) {
+                     int precision, const unsigned* in_absmax, hipStream_t st, const char* who, const LocateActEpilogue* epi = nullptr) {
     LOCATE_REQUIRE(precision >= 0 && precision <= 2, "%s: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)", who);
     LOCATE_REQUIRE(precision != 2 || in_absmax, "%s: precision 2 needs the gathered tensor's absmax word", who);
     IgParams p;
     p.precision = precision;
     p.b_absmax = in_absmax;
+    p.act_out = nullptr; p.act_bs = 0; p.lat = nullptr; p.lat_bs = 0; p.lat_z = 0;
     int nmax = 0;
     if (int e = conv_plan(g, adjoint | (precision == 2 ? 2 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
@@ -1710,6 +1732,12 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
     }
     LOCATE_REQUIRE(scale_bg >= 0 && (scale_bg == 0 || g.B % scale_bg == 0), "%s: batch %d is not a multiple of the scale group %d", who, g.B, scale_bg);
     LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
+    if (epi && epi->act_out) {
+        LOCATE_REQUIRE(skinny_ok(p), "%s: the activated second output exists for 1x1-map layers only", who);
+        LOCATE_REQUIRE(!epi->lat || (epi->lat_z > 0 && epi->act_bs >= epi->lat_z + g.M), "%s: bad latent prefix", who);
+        p.act_out = static_cast<float*>(epi->act_out); p.act_bs = epi->act_bs;
+        p.lat = static_cast<const float*>(epi->lat); p.lat_bs = epi->lat_bs; p.lat_z = epi->lat ? epi->lat_z : 0;
+    }
     return launch_igemm(p, nmax, ws, counters, st, who);
 }
 
@@ -1736,12 +1764,14 @@ LOCATE_API size_t locate_conv_counter_bytes(void) { return IG_MAX_COUNTERS * siz
 // tiles of mid-sized launches are combined inside the launch instead of by a second kernel.
 LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                                int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs,
-                               void* workspace, void* counters, int precision, const void* x_absmax, void* stream) {
+                               void* workspace, void* counters, int precision, const void* x_absmax, const void* act_epilogue,
+                               void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_fwd")) return e;
     LOCATE_REQUIRE(x && panel && y, "locate_conv_fwd: null pointer");
     return run_igemm(g, 0, x, x_bs, panel, scale, scale_group_batch, scale_stride, bias, y, y_bs, static_cast<float*>(workspace),
-                     static_cast<unsigned*>(counters), precision, static_cast<const unsigned*>(x_absmax), as_stream(stream), "locate_conv_fwd");
+                     static_cast<unsigned*>(counters), precision, static_cast<const unsigned*>(x_absmax), as_stream(stream), "locate_conv_fwd",
+                     static_cast<const LocateActEpilogue*>(act_epilogue));
 }
 
 // gx[b, c, i, j] = bias[c] + scale * sum_{m, kh, kw} gy[b, m, oh, ow] w[m, c, kh, kw],  i = oh*s - ph + kh, j = ow*s - pw + kw

@@ -168,6 +168,18 @@ class SpectralNorm(_Bound):
                         out if restore is _identity else None)
         return restore(y)
 
+    def forward_activated(self, x, latent=None):
+        """(layer(x), second) with second = RootTanh(layer(x)) - or, with `latent`, cat([latent, RootTanh(layer(x))], 1), the next
+        style link's input - from ONE launch where the layer runs on a 1x1 map (ops.act_epilogue_ok); None if it does not."""
+        m = self.module
+        x4, w4, spec, restore = self._plan(x)
+        if not ops.act_epilogue_ok(spec, x4.shape) or not x4.is_cuda:
+            return None
+        sigma, wv, guard = self.take_pre()
+        y, second = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard,
+                                None, {"latent": latent})
+        return restore(y), (second if latent is not None else restore(second))
+
 
 class _TwoBranch(nn.Module):
     """A skip branch and a layer branch over the same input (optionally a different input and a style scale for the layer
@@ -310,7 +322,27 @@ def feature_attention(in_size, features, dim=2, cfg=None):
         if conv.activated:
             parts.append(NonLinear())
     parts += [ChannelSoftmax(), Expand(-1, features, *([in_size] * dim))]
-    return nn.Sequential(*parts)
+    return _GateSequence(*parts)
+
+
+class _GateSequence(nn.Sequential):
+    """nn.Sequential (same positions = same state_dict keys) that runs a spectral-normalised conv on a 1x1 map together with
+    the RootTanh behind it as one launch (SpectralNorm.forward_activated)."""
+
+    def forward(self, x):
+        parts = list(self)
+        i = 0
+        while i < len(parts):
+            part = parts[i]
+            if isinstance(part, SpectralNorm) and i + 1 < len(parts) and isinstance(parts[i + 1], RootTanhModule) and x.is_cuda:
+                fused = part.forward_activated(x)
+                if fused is not None:
+                    x = fused[1]
+                    i += 2
+                    continue
+            x = part(x)
+            i += 1
+        return x
 
 
 class SelfAttention(nn.Module):
@@ -390,8 +422,17 @@ class LinearModule(nn.Module):
         return self.nlin(out), out
 
     def pre_activation(self, function_input):
-        """The linear alone; the activation is left to the consumer (BlockBlock fuses it with the next link's concatenation)."""
+        """The linear alone (the chain's last link: nothing consumes its activation)."""
         return self.module(function_input)
+
+    def pre_and_next_input(self, function_input, latent):
+        """(pre-activation, cat([latent, RootTanh(pre-activation)], 1)): the link's norm scale and the NEXT link's input
+        (libs/block.py:119-125) from one launch."""
+        fused = self.module.forward_activated(function_input, latent)
+        if fused is None:
+            pre = self.module(function_input)
+            return pre, ops.act_cat(latent, pre)
+        return fused
 
 
 class Block(nn.Module):
@@ -460,23 +501,19 @@ class BlockBlock(nn.Module):
         self.sums = self.first_style + [len(self.mul_blocks)] if mul_channel else [0]
         self.out_features = features[block_count]
 
-    def _style_scales(self, stage, latent, carry):
-        """Runs stage `stage`'s style linears: each sees [latent, previous activated output] and yields (a) its RootTanh
-        output - the next link's carry - and (b) its pre-activation as a [B, C, 1, 1] norm scale.  The activation of link k and
-        its concatenation with the latent are one launch, issued when link k + 1 needs them; that launch's autograd node also
-        hands out link k's scale (ops.act_cat_scale), so the scales lag one link behind: `carry` = (pre of the last link,
-        position of its still missing scale)."""
+    def _style_scales(self, stage, latent, carry, last_stage):
+        """Runs stage `stage`'s style linears: each sees [latent, previous activated output] (`carry`, written by the previous
+        link's own launch) and yields its pre-activation as a [B, C, 1, 1] norm scale plus the next link's input."""
         scales = []
         start = self.first_style[stage]
-        for linear in self.mul_blocks[start:start + len(self.plan[stage].style)]:
-            if carry is None:
-                inp = latent
+        links = self.mul_blocks[start:start + len(self.plan[stage].style)]
+        for k, linear in enumerate(links):
+            inp = latent if carry is None else carry
+            if last_stage and k == len(links) - 1:
+                pre, carry = linear.pre_activation(inp), None
             else:
-                inp, prev_scale = ops.act_cat_scale(latent, carry[0])
-                carry[1][carry[2]] = prev_scale                  # the previous link's scale, now that its node exists
-            pre = linear.pre_activation(inp)
-            scales.append(None)
-            carry = (pre, scales, len(scales) - 1)
+                pre, carry = linear.pre_and_next_input(inp, latent)
+            scales.append(pre.view(*pre.shape, 1, 1))
         return scales, carry
 
     def forward(self, function_input, noise=None):
@@ -485,15 +522,12 @@ class BlockBlock(nn.Module):
             for block in self.blocks:
                 out = block(out, scales=None)
             return out
-        # the whole style chain first (it depends on the latent alone): every link's scale comes out of the autograd node of
-        # the NEXT link's activation, the last link's is a plain view
+        # the whole style chain first (it depends on the latent alone)
         per_stage = []
+        last = max((i for i, st in enumerate(self.plan) if st.style), default=-1)
         for stage in range(len(self.blocks)):
-            scales, carry = self._style_scales(stage, noise, carry)
+            scales, carry = self._style_scales(stage, noise, carry, stage == last)
             per_stage.append(scales)
-        if carry is not None:
-            pre = carry[0]
-            carry[1][carry[2]] = pre.view(*pre.shape, 1, 1)
         for block, scales in zip(self.blocks, per_stage):
             out = block(out, scales=scales)
         return out

@@ -14,6 +14,12 @@ from ._lib import check, lib
 _IntArr12 = ctypes.c_int * 12
 
 
+class _ActEpilogue(ctypes.Structure):
+    """LocateActEpilogue of include/locate_hip.h: the activated second output of locate_conv_fwd on 1x1 maps."""
+    _fields_ = [("act_out", ctypes.c_void_p), ("act_bs", ctypes.c_int64), ("lat", ctypes.c_void_p), ("lat_bs", ctypes.c_int64),
+                ("lat_z", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -1025,9 +1031,10 @@ def _f16_ok(spec, geom, precision, *amax):
     return precision == 0 and spec.mode == "dense" and all(a is not None for a in amax) and _flops(geom) >= F16_MIN_FLOPS
 
 
-def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0, amax=None):
+def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0, amax=None, epilogue=None):
     """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode.
-    amax: x's largest-magnitude word, if its producer left one (fp16-piece form, panel format bit 2)."""
+    amax: x's largest-magnitude word, if its producer left one (fp16-piece form, panel format bit 2).
+    epilogue: _ActEpilogue (regular direction on a 1x1 map only) - RootTanh(y) written as a second output."""
     L = lib()
     st = _stream()
     _, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
@@ -1039,7 +1046,8 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
         if forward_of_r:
             ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
             check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                    _bs(y), _p(ws), _p(_counters(owner, 0)), prec, _p(am), st), "locate_conv_fwd")
+                                    _bs(y), _p(ws), _p(_counters(owner, 0)), prec, _p(am),
+                                    ctypes.addressof(epilogue) if epilogue is not None else None, st), "locate_conv_fwd")
         else:
             ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
             check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
@@ -1059,14 +1067,20 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
     return y
 
 
-def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0, amax=None, out=None):
+def act_epilogue_ok(spec, x_shape):
+    """The activated second output exists where the regular direction runs on a 1x1 map (skinny_rows_kernel)."""
+    return spec.kind == "conv" and spec.mode == "dense" and (spec.kh, spec.kw, spec.stride, spec.pad_h, spec.pad_w) == (1, 1, 1, 0, 0) \
+        and tuple(x_shape[2:]) == (1, 1)
+
+
+def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0, amax=None, out=None, epilogue=None):
     """y = conv(x, W_bar) / sigma + bias (Conv2d or ConvTranspose2d semantics per `spec`).  out: a dense-plane view of that
     shape to write into (a channel slice of a concatenation buffer) instead of a fresh tensor."""
     if out is not None and spec.mode == "dense" and tuple(out.shape) == tuple(out_shape) and _dense_planes(out) and out.dtype == torch.float32:
         y = out
     else:
         y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
-    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision, amax)
+    return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision, amax, epilogue)
 
 
 def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0, amax=None):
@@ -1178,7 +1192,7 @@ class SNConvFn(torch.autograd.Function):
     left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None, out_holder=None):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None, out_holder=None, act=None):
         # out_holder: [view] - the output is written into this channel slice of a concatenation buffer (hidden in a list so
         # that autograd does not see an input being returned)
         ctx.guard = guard              # (SpectralNormBatch, its ring sets): sigma / wv are views of them, still intact at backward?
@@ -1190,27 +1204,67 @@ class SNConvFn(torch.autograd.Function):
         b = _c(bias) if bias is not None else None
         rt = rt or DEFAULT_RUNTIME
         ctx.amax_x = _amax_of(x)
-        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x, out_holder[0] if out_holder else None)
+        # act = {"latent": [B, z] or None}: second output RootTanh(y) from the same launch (1x1 maps) - alone as [B, M, 1, 1], or
+        # as the next style link's input [B, z + M] = cat([latent, RootTanh(y)]) (libs/block.py:119-125)
+        epi = second = None
+        ctx.act_z = None
+        if act is not None:
+            Bn, Mn = out_shape[0], out_shape[1]
+            lat = act.get("latent")
+            z = 0 if lat is None else lat.shape[1]
+            second = torch.empty((Bn, z + Mn) if lat is not None else out_shape, dtype=torch.float32, device=x.device)
+            epi = _ActEpilogue(second.data_ptr() + 4 * z, z + Mn, _p(lat), 0 if lat is None else lat.stride(0), z, 0)
+            if lat is not None and (lat.stride(1) != 1 or lat.shape[0] != Bn):
+                raise ValueError("style latent must be [B, z] with contiguous rows")
+            ctx.act_z = z
+        y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x, out_holder[0] if out_holder else None, epi)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
         ctx.groups = groups
         if groups > 1:
             ctx.save_for_backward(x, w, sigma, wv, y, b)     # stacked: <G_k, W_bar> is taken on the activation side
+        elif second is not None:
+            ctx.save_for_backward(x, w, sigma, wv, y)        # RootTanh' of the second output needs the pre-activation
         else:
             ctx.save_for_backward(x, w, sigma, wv)
+        if second is not None:
+            ctx.set_materialize_grads(False)                 # an unused output's gradient arrives as None, not as a zero tensor
         ctx.u, ctx.v = u, v            # live state, read at backward time
         ctx.bias_param = bias
         ctx.owner = owner
         ctx.rt = rt
         ctx.geom, ctx.spec, ctx.has_bias = geom, spec, bias is not None
-        return y
+        if second is None:
+            return y
+        return y, second
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_second=None):
+        pre = None
         if ctx.groups > 1:
             x, w, sigma, wv, y, bsaved = ctx.saved_tensors
+            pre = y
+        elif ctx.act_z is not None:
+            x, w, sigma, wv, pre = ctx.saved_tensors
+            y = bsaved = None
         else:
             x, w, sigma, wv = ctx.saved_tensors
             y = bsaved = None
+        if ctx.act_z is not None and g_second is not None:
+            # gradient through the activated second output joins the pre-activation's own (a norm's style scale, or none):
+            # gy <- gy + RootTanh'(y) * g_second[:, z:]   - one launch (locate_act_rows_bwd), bit for bit autograd's sum
+            Bn, Mn = pre.shape[0], pre.shape[1]
+            g2 = _chk(g_second, "activated output gradient")
+            if g2.dim() != 2:
+                g2 = g2.reshape(Bn, -1)
+            if g2.stride(1) != 1:
+                g2 = g2.contiguous()
+            add = None if gy is None else _c(gy, "conv output gradient")
+            total = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
+            check(lib().locate_act_rows_bwd(_p(pre), g2.data_ptr() + 4 * ctx.act_z, g2.stride(0), _p(add), _p(total), Bn, Mn, _stream()),
+                  "locate_act_rows_bwd")
+            gy = total
+        if gy is None:
+            return (None,) * 12
         spec, garr = ctx.spec, _geom(ctx.geom)
         if ctx.guard is not None:
             ctx.guard[0].check(ctx.guard[1])
@@ -1250,13 +1304,14 @@ class SNConvFn(torch.autograd.Function):
             else:
                 gb = _bias_grad(gy)
         # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None, None, None, None
+        return gx, gw, gu, None, gb, None, None, None, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None, out=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None, out=None, act=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
-    batched update is supplied (guard: see SNConvFn.forward).  out: view to write the result into (see _conv_apply)."""
+    batched update is supplied (guard: see SNConvFn.forward).  out: view to write the result into (see _conv_apply).
+    act: see SNConvFn.forward - returns (y, second output) then."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard, None if out is None else [out])
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard, None if out is None else [out], act)

@@ -99,7 +99,7 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
 
     def r_fwd(inp, out):      # R forward
         check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, S()))
+                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, None, S()))
 
     def r_dgrad(inp, out):    # R data adjoint
         check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
