@@ -53,7 +53,7 @@ def parse():
     return ap.parse_args()
 
 
-PMC_RECORD = os.path.join(ROOT, "profiles", "r02_conv_pmc_mem.json")
+PMC_RECORD = os.path.join(ROOT, "profiles", "r03_conv_pmc_mem.json")
 
 
 def _pmc_traffic(flops_by_stage):
@@ -82,10 +82,12 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     = 2 * B * (2H * 2W) * C_out * C_in * 4 taps (each output pixel of a 4x4 s2 p1 transposed conv has 2x2 taps);
     algorithmic bytes per launch = weights + input + output once each, fp32 (4 (16 C^2 + B C H W + B C 2H 2W));
     time = HIP events on the launch stream around `reps` launches of each stage's forward.
-    fp32 line: the kernel computes fp32-faithful products on the bf16 matrix cores - both operands split exactly into three
-    bf16 pieces, six v_mfma_f32_32x32x16_bf16 per slice - so its roof is the dense bf16 MFMA peak
-    divided by the six instructions each algorithmic multiply-add costs: 2500 / 6 = 416.7 TFLOP/s (the fp32-input MFMA
-    peaks at 157.3).  bf16 line: one MFMA per slice, roof 2500."""
+    fp32 line: the kernel computes fp32-faithful products on the fp16 matrix cores - both operands scaled by a power of two and
+    split into two fp16 pieces (22 significant bits), three v_mfma_f32_32x32x16_f16 per slice (hh, hl, lh) -
+    so its roof is the dense fp16 MFMA peak divided by the three instructions each algorithmic multiply-add costs:
+    2500 / 3 = 833.3 TFLOP/s algorithmic, i.e. `frac` = executed MFMA TFLOP/s / 2500.  (Round 2's three-piece bf16 form executed
+    six: 141 TF algorithmic = 0.34 of ITS roof 416.7; the two-piece form is ~1.35x faster and sits LOWER against its higher
+    roof - the frac falls while the time improves.)  bf16 line: one MFMA per slice, roof 2500."""
     from locate_amd import ops
     from locate_amd.models import generator_features
     feats = generator_features(cfg)
@@ -93,6 +95,7 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     rt.precision = 1 if bf16 else 0
     total_flops, total_ms, rows, flops_list, alg_bytes = 0.0, 0.0, [], [], 0.0
     size = 2
+    calls0 = ops.F16_CALLS["fwd"]
     for i in range(len(feats) - 1):
         c = feats[i]
         if c >= 96 and i >= 1:
@@ -100,6 +103,8 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
             u = torch.randn(c, device=dev)
             v = torch.randn(c * 16, device=dev)
             x = torch.randn(batch, c, size, size, device=dev)
+            if not bf16:
+                ops.tag_amax(x)      # in the step the producing kernel (norm + RootTanh) leaves this word; it selects the fp16-piece form
             spec = ops.ConvSpec("convT", 4, 4, 2, 1, 1)
             pre = ops.sn_power_iteration(w, u, v)
             with torch.no_grad():
@@ -120,25 +125,33 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
             flops_list.append(flops)
             alg_bytes += nbytes * flops
         size *= 2
+    f16 = (not bf16) and ops.F16_CALLS["fwd"] > calls0
     achieved = total_flops / total_ms / 1e9 if total_ms > 0 else 0.0
     alg_bytes = alg_bytes / total_flops if total_flops else 0.0          # FLOP-weighted mean per launch, like `traffic`
     traffic, source = (None, "not collected for the bf16 variant") if bf16 else _pmc_traffic(flops_list)
-    peak = 2500.0 if bf16 else round(2500.0 / 6.0, 1)
-    out = {"bound": "mfma",
-           "kernel": ("conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 slice, fp32 accumulate, "
-                      "ConvTranspose 4x4 s2 fwd)") if bf16 else
-                     ("conv_igemm_bx6_kernel (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per 32x32x16 slice, "
-                      "ConvTranspose 4x4 s2 fwd)"),
+    per_madd = 1 if bf16 else (3 if f16 else 6)
+    peak = round(2500.0 / per_madd, 1)
+    if bf16:
+        kernel = "conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 slice, fp32 accumulate, ConvTranspose 4x4 s2 fwd)"
+    elif f16:
+        kernel = ("conv_igemm_bx6_kernel<NP=2> (implicit GEMM, fp32-faithful: 2 x fp16 scaled operand pieces, 3 fp16 MFMAs per 32x32x16 "
+                  "slice, ConvTranspose 4x4 s2 fwd)")
+    else:
+        kernel = ("conv_igemm_bx6_kernel<NP=3> (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per 32x32x16 slice, "
+                  "ConvTranspose 4x4 s2 fwd)")
+    out = {"bound": "mfma", "kernel": kernel,
            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            "traffic": None if traffic is None else round(traffic), "traffic_source": source,
            "algorithmic_bytes": round(alg_bytes), "per_stage": rows}
     if not bf16:
-        out.update({"executed_bf16_mfma_tflops": round(6 * achieved, 1), "bf16_dense_peak": 2500.0, "fp32_mfma_peak": 157.3,
-                    # what a bare bf16 MFMA loop sustains on RANDOM operands (the chip lowers its clock under matrix load:
-                    # MI355X_MICROARCH.md "DVFS give-back" measures 1247 TF there, 1483 on zeros); `frac` above stays against
-                    # the nominal peak, this is the same figure against that ceiling (profiles/r02_patch_form_ab.txt: these
-                    # launches run 15-18 % faster on all-zero operands - they are clock-bound)
-                    "sustained_bf16_mfma_on_random_data": 1247.0, "frac_of_sustained": round(6 * achieved / 1247.0, 4)})
+        out.update({"mfma_per_multiply_add": per_madd, "executed_mfma_tflops": round(per_madd * achieved, 1), "dense_mfma_peak": 2500.0,
+                    "fp32_mfma_peak": 157.3,
+                    "note": "achieved = ALGORITHMIC TFLOP/s; frac = achieved / (2500 / mfma_per_multiply_add) = executed matrix-core TFLOP/s / "
+                            "2500.  Round 2 (six bf16 MFMAs per multiply-add): 141 TF algorithmic, 846 executed, frac 0.34; the two-piece "
+                            "fp16 form executes half the instructions, so the time drops (~0.13 -> ~0.10 ms per stage) while frac drops too",
+                    # what a bare MFMA loop sustains on RANDOM operands (the chip lowers its clock under matrix load:
+                    # MI355X_MICROARCH.md "DVFS give-back" measures 1247 TF there, 1483 on zeros)
+                    "sustained_mfma_on_random_data": 1247.0, "frac_of_sustained": round(per_madd * achieved / 1247.0, 4)})
     return out
 
 
@@ -199,7 +212,7 @@ def hbm_bound_block(batch, dev, reps=10):
             ws_g = torch.empty(max(L.locate_gate_bwd_workspace_bytes(planes), 16), dtype=torch.uint8, device=dev)
             add("gate fwd", shape, 2 * n_gate, 12 * n, lambda: check(L.locate_gate_fwd(P(x), P(a), 0, P(gam), P(y), planes, hw, st)))
             add("gate bwd", shape, n_gate, 20 * n,
-                lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, st)))
+                lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, None, st)))
         if (C, H) in ((48, 64), (192, 16)):
             add("softmax over H*W fwd", shape, 2, 8 * n, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)))
             add("softmax over H*W bwd", shape, 1, 12 * n, lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)))
@@ -370,7 +383,8 @@ def main():
             "metric": "images/sec (G+D step) %dx%d bs=%d" % (S, S, B), "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions: exact 3 x bf16 operand splits on the bf16 MFMA, fp32 accumulate)" if args.dtype == "fp32" else
+            "dtype": "f32 (contractions fp32-faithful on the matrix cores: 2 x scaled fp16 operand pieces / 3 MFMAs per slice where the operand's "
+                     "largest magnitude comes with it, else 3 x bf16 pieces / 6 MFMAs; fp32 accumulate)" if args.dtype == "fp32" else
                      "bf16 (contraction operands rounded to bf16, one MFMA per slice, fp32 accumulate; storage, statistics, "
                      "sigma, activations and Nadam fp32) - NOT the headline line, see --dtype fp32", "data": "synthetic",
             "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (%s of BASELINE.json configs[1]: 64x64 RGB bs 64), "

@@ -90,7 +90,7 @@ size_t locate_gate_bwd_workspace_bytes(int64_t planes);
 int locate_gate_bwd_partials(int64_t planes, int hw);
 int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g, float* dx, float* da,
                     float* dgamma, int64_t planes, int hw, void* workspace, int accumulate_dx,
-                    void* stream);
+                    void* da_absmax /* nullable: largest |da| (full-map form), see locate_roottanh_bwd */, void* stream);
 
 /* ---- softmax over the last dimension of [rows, n] (libs/attention.py:35,47) ---- */
 int locate_softmax_fwd(const float* x, float* y, int64_t rows, int n, void* stream);

@@ -45,7 +45,7 @@ PROTOTYPES = {
     "locate_gate_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "locate_gate_fwd_stats": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "locate_gate_bwd_workspace_bytes": (c_sz, [c_i64]),
-    "locate_gate_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),
+    "locate_gate_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_i, c_p, c_p]),
     "locate_softmax_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_p]),
     "locate_softmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "locate_upsample2x_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),

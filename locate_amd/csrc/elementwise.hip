@@ -258,9 +258,12 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ g,
                                                              float* __restrict__ dx, float* __restrict__ da_full,
                                                              float* __restrict__ da_plane, double* __restrict__ block_x2g,
-                                                             int64_t planes, int hw, int a_per_plane, int accumulate_dx) {
+                                                             int64_t planes, int hw, int a_per_plane, int accumulate_dx,
+                                                             unsigned* __restrict__ da_absmax) {
     __shared__ double wsum[4], px2g[4];
     __shared__ float pxg[4];
+    __shared__ float amax_scratch[16];
+    float am = 0.0f;                    // largest |da| (full-map form): the branch's last conv consumes da in its fp16-piece form
     double wacc = 0.0;
     const float gm = gamma[0];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -287,7 +290,11 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                     o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
                 }
                 reinterpret_cast<float4*>(dx + base)[i] = o;
-                if (!a_per_plane) reinterpret_cast<float4*>(da_full + base)[i] = make_float4(xg.x * gm, xg.y * gm, xg.z * gm, xg.w * gm);
+                if (!a_per_plane) {
+                    const float4 dav = make_float4(xg.x * gm, xg.y * gm, xg.z * gm, xg.w * gm);
+                    reinterpret_cast<float4*>(da_full + base)[i] = dav;
+                    am = fmaxf(fmaxf(am, fmaxf(fabsf(dav.x), fabsf(dav.y))), fmaxf(fabsf(dav.z), fabsf(dav.w)));
+                }
                 sxg += (xg.x + xg.y) + (xg.z + xg.w);
                 sx2g += (xg.x * xv.x + xg.y * xv.y) + (xg.z * xv.z + xg.w * xv.w);
             }
@@ -298,7 +305,7 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
                 const float xg = xv * gv;
                 const float o = fmaf(gm, av, 1.0f) * gv;
                 dx[base + i] = accumulate_dx ? dx[base + i] + o : o;
-                if (!a_per_plane) da_full[base + i] = xg * gm;
+                if (!a_per_plane) { da_full[base + i] = xg * gm; am = fmaxf(am, fabsf(xg * gm)); }
                 sxg += xg;
                 sx2g = fmaf(xg, xv, sx2g);
             }
@@ -325,6 +332,7 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
     } else if (threadIdx.x == 0) {
         block_x2g[blockIdx.x] = wacc;
     }
+    if (da_absmax && !a_per_plane) absmax_publish(am, amax_scratch, da_absmax);
 }
 
 // dgamma = sum over blocks of block_x2g (reference bug: x^2 g, merge.py:33-38)
@@ -376,7 +384,7 @@ LOCATE_API int locate_gate_bwd_partials(int64_t planes, int hw) { return (int)ga
 // blocks taking a ticket from ONE counter serialise at ~90 arrivals per microsecond: +0.7 ms per training step.)
 LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, const float* gamma, const float* g,
                                float* dx, float* da, float* dgamma, int64_t planes, int hw, void* workspace,
-                               int accumulate_dx, void* stream) {
+                               int accumulate_dx, void* da_absmax, void* stream) {
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
     double* block_x2g = static_cast<double*>(workspace);
     const bool whole_block = hw >= 1024;
@@ -384,11 +392,11 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
     if (whole_block)
         gate_bwd_plane_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
-                                                                            a_per_plane, accumulate_dx);
+                                                                            a_per_plane, accumulate_dx, static_cast<unsigned*>(da_absmax));
     else
         gate_bwd_plane_kernel<1><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
-                                                                            a_per_plane, accumulate_dx);
+                                                                            a_per_plane, accumulate_dx, static_cast<unsigned*>(da_absmax));
     LOCATE_LAUNCH_CHECK("locate_gate_bwd(plane)");
     if (!dgamma) return LOCATE_OK;       // the caller sums the locate_gate_bwd_partials() doubles in `workspace` itself, or needs none
     gate_bwd_final_kernel<<<1, 256, 0, as_stream(stream)>>>(block_x2g, dgamma, (int)blocks);

@@ -56,25 +56,39 @@ class _AmaxArena:
     (`_locate_amax`).  A tensor without one (any other producer, a gradient autograd had to sum, a non-contiguous view that
     was copied) simply takes the six-product path: same fp32-level results, nothing is ever guessed.
 
-    Words come from small zeroed blocks, each handed out once (never reused: no aliasing between passes or networks); a new
-    block costs one fill launch per forward / backward pass."""
-    SLOTS = 32
+    Words come from zeroed blocks, each word set handed out once (never reused: no aliasing between passes or networks); a
+    new block costs one fill launch.  The step driver starts one block per training iteration (new_step: ~90 tensors);
+    stand-alone use simply takes a new block whenever the current one is used up."""
+    SLOTS = 32            # per block when nobody announced a step
+    STEP_SLOTS = 160      # per training iteration (TrainStep): two generator and two discriminator forwards, three backward passes
 
     def __init__(self):
-        self.block, self.used = None, 0
+        self.block, self.used, self.cap = None, 0, 0
         self.enabled = True
         self.words = None            # words per tensor (locate_absmax_words: producers spread their atomics over them)
+        self._step = False
 
     def new_pass(self):
+        """A forward / backward pass begins: outside a training iteration it gets a block of its own."""
+        if not self._step:
+            self.block = None
+
+    def new_step(self):
+        """A training iteration begins (TrainStep.d_generate): ONE block serves all its passes."""
         self.block = None
+        self._step = True
+
+    def end_step(self):
+        self._step = False
 
     def slot(self, device):
         if not self.enabled:
             return None
         if self.words is None:
             self.words = lib().locate_absmax_words()
-        if self.block is None or self.used >= self.SLOTS or self.block.device != device:
-            self.block = torch.zeros(self.SLOTS * self.words, dtype=torch.int32, device=device)
+        if self.block is None or self.used >= self.cap or self.block.device != device:
+            self.cap = self.STEP_SLOTS if self._step else self.SLOTS
+            self.block = torch.zeros(self.cap * self.words, dtype=torch.int32, device=device)
             self.used = 0
         s = self.block[self.used * self.words:(self.used + 1) * self.words]
         self.used += 1
@@ -650,8 +664,12 @@ class GateFn(torch.autograd.Function):
         deferred = need_gamma and rt.defer_finalisers and ctx.gamma_param.is_leaf
         dgamma = torch.empty_like(gamma) if need_gamma else None
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
+        # full-map form: da goes straight into the branch's last conv (its data and weight gradients) - with its largest magnitude
+        amax = AMAX.slot(x.device) if (not ctx.per_plane and da.numel() >= (1 << 16)) else None
         check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), None if deferred else _p(dgamma),
-                                planes, hw, _p(ws), acc, _stream()), "locate_gate_bwd")
+                                planes, hw, _p(ws), acc, _p(amax), _stream()), "locate_gate_bwd")
+        if amax is not None:
+            da._locate_amax = amax
         if deferred:
             rt.queue_sum(ws, L.locate_gate_bwd_partials(planes, hw), dgamma)
             rt.late_grad(ctx.gamma_param, dgamma.view(ctx.gamma_param.shape))

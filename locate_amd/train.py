@@ -128,6 +128,8 @@ class TrainStep:
 
     def d_generate(self, latent):
         """main.py:146: the D-step's generator pass (the reference builds a graph and drops it with .detach())."""
+        from . import ops
+        ops.AMAX.new_step()            # the iteration's first phase: one zeroed block of largest-magnitude words for all its passes
         with torch.no_grad():
             return self.gen(latent)
 
@@ -233,8 +235,10 @@ class TrainStep:
         return {"g_error": loss[0], "fake": fake.detach()}
 
     def g_optimizer(self):
+        from . import ops
         self.gen_opt.step()                        # :171
         self._repack(self.gen)
+        ops.AMAX.end_step()
 
     def d_step(self, latent, real, aug):
         out = self.d_forward_backward(latent, real, aug)

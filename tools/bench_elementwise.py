@@ -68,9 +68,9 @@ def main():
         gam, dgam = torch.full((1,), 2.0, device=dev), torch.empty(1, device=dev)
         ws_g = torch.empty(max(L.locate_gate_bwd_workspace_bytes(planes), 16), dtype=torch.uint8, device=dev)
         report("gate, full attention map", shape, lambda: check(L.locate_gate_fwd(P(x), P(a), 0, P(gam), P(y), planes, hw, st)),
-               lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, st)), 3 * n, 5 * n)
+               lambda: check(L.locate_gate_bwd(P(x), P(a), 0, P(gam), P(g), P(gx), P(da), P(dgam), planes, hw, P(ws_g), 0, None, st)), 3 * n, 5 * n)
         report("gate, per-plane attention", shape, lambda: check(L.locate_gate_fwd(P(x), P(ac), 1, P(gam), P(y), planes, hw, st)),
-               lambda: check(L.locate_gate_bwd(P(x), P(ac), 1, P(gam), P(g), P(gx), P(dac), P(dgam), planes, hw, P(ws_g), 0, st)), 2 * n, 3 * n)
+               lambda: check(L.locate_gate_bwd(P(x), P(ac), 1, P(gam), P(g), P(gx), P(dac), P(dgam), planes, hw, P(ws_g), 0, None, st)), 2 * n, 3 * n)
         report("softmax over H*W", shape, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)),
                lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)), 2 * n, 3 * n)
         if H == 64:

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--bf16-pieces", action="store_true", help="the three-piece bf16 form (six MFMAs per slice) instead of the fp16-piece form")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rt = ops.Runtime()
@@ -28,6 +29,8 @@ def main():
         w = torch.randn(c, c, 4, 4, device=dev) * 0.05
         u, v = torch.randn(c, device=dev), torch.randn(c * 16, device=dev)
         x = torch.randn(args.batch, c, size, size, device=dev)
+        if not (args.bf16 or args.bf16_pieces):
+            ops.tag_amax(x)          # the producing kernel's job in the step: selects the two-piece fp16 form (precision 2)
         pre = ops.sn_power_iteration(w, u, v)
         with torch.no_grad():
             for _ in range(args.reps + 1):           # the first call also packs the weight panel
