@@ -16,6 +16,14 @@ __device__ __forceinline__ void bil_src(int dst, int size, int& i0, int& i1, flo
     l0 = 1.0f - l1;
 }
 
+// One output of the bilinear stencil, with the roundings spelled out (two products, two fused multiply-adds per row pair) so that
+// every kernel variant below rounds the same way whatever the compiler would contract: they agree bit for bit.
+__device__ __forceinline__ float bil_eval(float ly0, float ly1, float lx0, float lx1, float a0, float a1, float b0, float b1) {
+    const float top = __fmaf_rn(lx1, a1, __fmul_rn(lx0, a0));
+    const float bot = __fmaf_rn(lx1, b1, __fmul_rn(lx0, b0));
+    return __fmaf_rn(ly1, bot, __fmul_rn(ly0, top));
+}
+
 __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t planes, int H, int W) {
     const int OH = 2 * H, OW = 2 * W;
@@ -32,7 +40,7 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __rest
         bil_src(oy, H, y0, y1, ly0, ly1);
         bil_src(ox, W, x0, x1, lx0, lx1);
         const float* xp = x + (int64_t)p * H * W;
-        y[i] = ly0 * (lx0 * xp[y0 * W + x0] + lx1 * xp[y0 * W + x1]) + ly1 * (lx0 * xp[y1 * W + x0] + lx1 * xp[y1 * W + x1]);
+        y[i] = bil_eval(ly0, ly1, lx0, lx1, xp[y0 * W + x0], xp[y0 * W + x1], xp[y1 * W + x0], xp[y1 * W + x1]);
     }
 }
 
@@ -60,9 +68,71 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_vec_kernel(const float* __
             int x0, x1;
             float lx0, lx1;
             bil_src(4 * (int)j + e, W, x0, x1, lx0, lx1);
-            out[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            out[e] = bil_eval(ly0, ly1, lx0, lx1, r0[x0], r0[x1], r1[x0], r1[x1]);
         }
         reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// W a multiple of 4: one thread per 2 x 8 OUTPUT patch (rows 2k, 2k + 1; columns 8j .. 8j + 7), which reads input rows
+// k - 1 .. k + 1 and columns 4j - 1 .. 4j + 4 (clamped): per row one aligned 16-byte load plus the two edge columns - nine load
+// instructions for sixteen results (the four-wide kernel above: eight for four; the bilinear kernels were bound by their load
+// ISSUE rate, 0.28 of the HBM peak at 64 x 64) and four 16-byte stores.  Same expression, weights and source elements per output
+// as the scalar kernel: bit-identical results.
+__global__ void __launch_bounds__(256) upsample2x_fwd_tile_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int64_t planes, int H, int W) {
+    const int OW = 2 * W, W4 = W / 4;
+    const unsigned n = (unsigned)(planes * H * W4);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)W4), dh((unsigned)H);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, uj, p, uk;
+        dw.divmod(i, t, uj);
+        dh.divmod(t, p, uk);
+        const int j = (int)uj, k = (int)uk;
+        const float* xp = x + (int64_t)p * H * W;
+        float v[3][6];                       // v[s][c]: input row clamp(k - 1 + s), column clamp(4j - 1 + c)
+        const int cl = 4 * j - 1 < 0 ? 0 : 4 * j - 1, cr = 4 * j + 4 > W - 1 ? W - 1 : 4 * j + 4;
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            int r = k - 1 + s2;
+            r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+            const float* rp = xp + (int64_t)r * W;
+            const float4 mid = *reinterpret_cast<const float4*>(rp + 4 * j);
+            v[s2][0] = rp[cl]; v[s2][1] = mid.x; v[s2][2] = mid.y; v[s2][3] = mid.z; v[s2][4] = mid.w; v[s2][5] = rp[cr];
+        }
+        const bool top = k == 0, bottom = k == H - 1, left = j == 0, right = 4 * j + 3 == W - 1;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            int y0, y1;
+            float ly0, ly1;
+            bil_src(2 * k + o, H, y0, y1, ly0, ly1);
+            // local rows of (y0, y1): output row 2k reads rows (k - 1, k) - at the top edge (k, k + 1) with weight 0 on the
+            // second -, output row 2k + 1 rows (k, k + 1) - at the bottom edge (k, k)
+            float a[6], b[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                a[c] = o == 0 ? (top ? v[1][c] : v[0][c]) : v[1][c];
+                b[c] = o == 0 ? (top ? v[2][c] : v[1][c]) : (bottom ? v[1][c] : v[2][c]);
+            }
+            float out[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int x0, x1;
+                float lx0, lx1;
+                bil_src(8 * j + e, W, x0, x1, lx0, lx1);
+                // local columns: output column 8j + e reads columns 4j + floor((e - 1) / 2) and the next one; the first output of
+                // the row (source clamped to column 0) and the last one (no column to the right) are the exceptions
+                const int c0 = (e + 1) / 2;                      // e = 0 -> 0, 1,2 -> 1, 3,4 -> 2, 5,6 -> 3, 7 -> 4
+                float a0 = a[c0], a1 = a[c0 + 1], b0 = b[c0], b1 = b[c0 + 1];
+                if (e == 0) { a0 = left ? a[1] : a0; a1 = left ? a[2] : a1; b0 = left ? b[1] : b0; b1 = left ? b[2] : b1; }
+                if (e == 7) { a1 = right ? a[4] : a1; b1 = right ? b[4] : b1; }
+                out[e] = bil_eval(ly0, ly1, lx0, lx1, a0, a1, b0, b1);
+            }
+            float4* yp = reinterpret_cast<float4*>(y + ((int64_t)p * 2 * H + 2 * k + o) * OW + 8 * j);
+            yp[0] = make_float4(out[0], out[1], out[2], out[3]);
+            yp[1] = make_float4(out[4], out[5], out[6], out[7]);
+        }
     }
 }
 
@@ -258,7 +328,9 @@ __global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __re
 // x: [planes, H, W] -> y: [planes, 2H, 2W]
 LOCATE_API int locate_upsample2x_fwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
     LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_upsample2x_fwd: bad shape");
-    if ((W & 1) == 0 && ((uintptr_t)b & 15) == 0)
+    if ((W & 3) == 0 && W >= 8 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0)
+        upsample2x_fwd_tile_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    else if ((W & 1) == 0 && ((uintptr_t)b & 15) == 0)
         upsample2x_fwd_vec_kernel<<<stream_grid(planes * 2 * H * (W / 2), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
     else
         upsample2x_fwd_kernel<<<stream_grid(planes * 4 * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);

@@ -513,10 +513,12 @@ def test_indexing_bit_exact_and_resampling():
     assert_close(t.grad.cpu(), z["expand_dx"], 1e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (2, 3, 4, 6), (3, 5, 8, 8), (1, 2, 2, 2), (2, 4, 6, 12), (2, 2, 1, 1), (64, 6, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (2, 3, 4, 6), (3, 5, 8, 8), (1, 2, 2, 2), (2, 4, 6, 12), (2, 2, 1, 1), (64, 6, 32, 32),
+                                   (2, 3, 3, 16), (1, 1, 1, 8), (5, 7, 16, 16)])
 def test_resampling_shapes_vs_aten(shape):
     """Bilinear x2 and 2x2 average pooling (forward and backward) against ATen on odd / even / vectorisable widths: the
-    scalar and the 16-byte-store kernels must agree with the same reference."""
+    scalar, the 16-byte-store and the 2 x 8 patch kernels (W a multiple of 4, from 8 up: odd heights, one-row maps) must agree
+    with the same reference."""
     from locate_amd import ops
     torch.manual_seed(sum(shape))
     x = torch.randn(shape)
@@ -837,3 +839,22 @@ def test_forked_tensor_second_backward_kernel_accumulates(first, second):
         if got is None and want is None:
             continue
         assert_close(got.cpu(), want.cpu(), 2e-6, name)
+
+
+@pytest.mark.gpu
+def test_upsample_kernel_variants_agree_bit_for_bit():
+    """The three forward kernels of the bilinear x2 upsample (scalar, four-wide, 2 x 8 patch) are picked by width and alignment;
+    they evaluate the same stencil with the same roundings: a tensor wide enough for the patch kernel, and the same values seen
+    through a view whose rows start 4 bytes off 16-byte alignment (scalar kernel), must give identical bits."""
+    from locate_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(3, 4, 8, 16, device=dev())
+    y_tile = ops.upsample2x(x)                                   # W = 16: the 2 x 8 patch kernel
+    wide = torch.randn(3, 4, 8, 18, device=dev())
+    wide[..., 1:17] = x
+    y_wide = ops.upsample2x(wide)                                # W = 18: the four-wide kernel; interior columns see the same stencil
+    assert torch.equal(y_tile[..., 2:30], y_wide[..., 4:32])
+    odd = torch.randn(3, 4, 8, 17, device=dev())
+    odd[..., :16] = x
+    y_odd = ops.upsample2x(odd)                                  # W = 17: the scalar kernel
+    assert torch.equal(y_tile[..., :30], y_odd[..., :30])
