@@ -2540,13 +2540,22 @@ static PwPlan pw_plan(const ConvGeom& g) {
 // sum over the 64 ... 192 batch rows.  lane = c (x[n][.] is one coalesced load), a block owns eight rows m (gy[n][m .. m + 7] is
 // wave-uniform: one scalar load) and its four waves a quarter of the batch each, plain fp32 FMAs, no slab; one partial of
 // <unscaled gw, W_bar> per block.
+// OnePix (hw > 0): the layer maps its whole H x W input to ONE output pixel (the discriminator's last 5x5 s2 conv on a 2 x 2
+// map, its 3x3 head on a 1 x 1 map: 6.5 M of D's 11.6 M parameters).  Only the taps that meet the input carry a gradient -
+// 4 of 25, 1 of 9 - and that gradient is the same outer-product sum over the batch with x viewed as [B, C H W]: the kernel
+// below with its columns scattered to their taps and the other taps zeroed (the general kernel multiplies through all 25 taps'
+// columns on the fp32 MFMA - these layers' OW is odd - for 21 exact zeros out of 25).
+struct OnePix {
+    int hw, W, KH, KW, pad_h, pad_w, Cw;
+};
+
 #define SKW_MT 8          // gradient rows per block
 #define SKW_NC 32         // batch rows per load batch
 
 __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
                                                            long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
                                                            const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
-                                                           double* __restrict__ partial, int N, int M, int C) {
+                                                           double* __restrict__ partial, int N, int M, int C, OnePix op) {
     __shared__ double scratch[16];
     __shared__ float red[4][SKW_MT][64];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -2588,9 +2597,26 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
         const int t = wid * (SKW_MT / 4) + q;
         if (jok && i0 + t < M) {
             const float v = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
-            const long long o = (long long)(i0 + t) * C + j;
-            if (w_ref) dot += (double)v * (double)w_ref[o];
-            gw[o] = v * sc;
+            long long o = (long long)(i0 + t) * C + j;
+            bool inside = true;
+            if (op.hw > 0) {           // column j = (c, iy, ix) of a whole input map: tap (iy + pad_h, ix + pad_w) of weight row (m, c)
+                const int c = j / op.hw, pix = j - c * op.hw;
+                const int iy = pix / op.W, ix = pix - iy * op.W;
+                const int kh = iy + op.pad_h, kw = ix + op.pad_w;
+                inside = kh < op.KH && kw < op.KW;           // pixels no tap of the single output position reaches
+                o = (((long long)(i0 + t) * op.Cw + c) * op.KH + kh) * op.KW + kw;
+            }
+            if (inside) {
+                if (w_ref) dot += (double)v * (double)w_ref[o];
+                gw[o] = v * sc;
+            }
+            if (op.hw > 0 && j % op.hw == 0) {          // the lane of pixel 0 of (m, c) zeroes the taps no input pixel reaches
+                const int c = j / op.hw, H = op.hw / op.W;
+                float* row = gw + ((long long)(i0 + t) * op.Cw + c) * op.KH * op.KW;
+                for (int kh = 0; kh < op.KH; ++kh)
+                    for (int kw = 0; kw < op.KW; ++kw)
+                        if (!(kh >= op.pad_h && kh - op.pad_h < H && kw >= op.pad_w && kw - op.pad_w < op.W)) row[kh * op.KW + kw] = 0.0f;
+            }
         }
     }
     if (partial) {
@@ -2604,10 +2630,15 @@ static bool skinny_wgrad_ok(const ConvGeom& g) {
            g.W == 1 && g.OH == 1 && g.OW == 1;
 }
 static dim3 skinny_wgrad_grid(const ConvGeom& g) { return dim3((g.C + 63) / 64, (g.M + SKW_MT - 1) / SKW_MT); }
+// one output pixel, a kernel larger than 1x1 (see OnePix); the input map is small by construction (it fits under the kernel)
+static bool onepix_wgrad_ok(const ConvGeom& g) {
+    return !path_disabled("skinny") && !skinny_wgrad_ok(g) && g.OH == 1 && g.OW == 1 && (long long)g.C * g.H * g.W < (1 << 24);
+}
+static dim3 onepix_wgrad_grid(const ConvGeom& g) { return dim3((g.C * g.H * g.W + 63) / 64, (g.M + SKW_MT - 1) / SKW_MT); }
 
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
     const ConvGeom g = make_geom(geom);
-    if (skinny_wgrad_ok(g)) return 0;
+    if (skinny_wgrad_ok(g) || onepix_wgrad_ok(g)) return 0;
     {
         const PwPlan q = pw_plan(g);
         if (q.ok) return (size_t)q.nslab * g.M * g.C * sizeof(float);
@@ -2622,6 +2653,10 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
     const ConvGeom g = make_geom(geom);
     if (skinny_wgrad_ok(g)) {
         const dim3 grid = skinny_wgrad_grid(g);
+        return (int)(grid.x * grid.y);
+    }
+    if (onepix_wgrad_ok(g)) {
+        const dim3 grid = onepix_wgrad_grid(g);
         return (int)(grid.x * grid.y);
     }
     {
@@ -2653,8 +2688,15 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     hipStream_t st = as_stream(stream);
     if (skinny_wgrad_ok(g)) {          // 1x1 maps: plain fp32 FMAs at either precision setting (see skinny_rows_kernel)
         skinny_wgrad_kernel<<<skinny_wgrad_grid(g), 256, 0, st>>>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_group_batch, scale_stride,
-                                                                  inner_partial, g.B, g.M, g.C);
+                                                                  inner_partial, g.B, g.M, g.C, OnePix{0, 0, 0, 0, 0, 0, 0});
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(1x1 map)");
+        return LOCATE_OK;
+    }
+    if (onepix_wgrad_ok(g)) {          // one output pixel: the useful taps only; the kernel zeroes the others itself (see OnePix)
+        const OnePix op = {g.H * g.W, g.W, g.KH, g.KW, g.pad_h, g.pad_w, g.C};
+        skinny_wgrad_kernel<<<onepix_wgrad_grid(g), 256, 0, st>>>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_group_batch, scale_stride,
+                                                                  inner_partial, g.B, g.M, g.C * g.H * g.W, op);
+        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(one output pixel)");
         return LOCATE_OK;
     }
     const PwPlan pq = pw_plan(g);
