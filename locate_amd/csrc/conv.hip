@@ -2610,12 +2610,25 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
                 if (w_ref) dot += (double)v * (double)w_ref[o];
                 gw[o] = v * sc;
             }
-            if (op.hw > 0 && j % op.hw == 0) {          // the lane of pixel 0 of (m, c) zeroes the taps no input pixel reaches
-                const int c = j / op.hw, H = op.hw / op.W;
-                float* row = gw + ((long long)(i0 + t) * op.Cw + c) * op.KH * op.KW;
-                for (int kh = 0; kh < op.KH; ++kh)
-                    for (int kw = 0; kw < op.KW; ++kw)
-                        if (!(kh >= op.pad_h && kh - op.pad_h < H && kw >= op.pad_w && kw - op.pad_w < op.W)) row[kh * op.KW + kw] = 0.0f;
+        }
+    }
+    if (op.hw > 0) {
+        // the taps no input pixel reaches get their zeros here: the block owns rows i0 .. i0 + 7 of the channels its 64 columns
+        // span - contiguous runs of gw - and walks them with consecutive lanes on consecutive addresses, skipping the taps the
+        // code above wrote (disjoint addresses: no ordering needed).  A channel whose pixels straddle two blocks is zeroed by
+        // the block that holds its pixel 0.
+        const int H = op.hw / op.W, taps = op.KH * op.KW;
+        const int first_col = blockIdx.x * 64;
+        const int c_first = (first_col + op.hw - 1) / op.hw;
+        int c_last = (first_col + 63) / op.hw;
+        if (c_last > op.Cw - 1) c_last = op.Cw - 1;
+        const int span = (c_last - c_first + 1) * taps;
+        for (int t = 0; t < SKW_MT; ++t) {
+            if (i0 + t >= M) break;
+            float* row = gw + ((long long)(i0 + t) * op.Cw + c_first) * taps;
+            for (int e = threadIdx.x; e < span; e += blockDim.x) {
+                const int tap = e % taps, kh = tap / op.KW, kw = tap - kh * op.KW;
+                if (!(kh >= op.pad_h && kh - op.pad_h < H && kw >= op.pad_w && kw - op.pad_w < op.W)) row[e] = 0.0f;
             }
         }
     }
