@@ -29,11 +29,14 @@ def time_it(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64,
+                    help="64: the step's own tensors (48-100 MB: they fit the 256 MB Infinity Cache between producer and consumer); 256: "
+                         "192-400 MB per operand - every pass really goes to HBM")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = lib()
     st = torch.cuda.current_stream().cuda_stream
-    B = 64
+    B = args.batch
     print("%-30s %-16s %28s %28s" % ("op", "tensor", "forward  ms | GB/s | of peak", "backward ms | GB/s | of peak"))
 
     def report(name, shape, fwd, bwd, fe, be):

@@ -1,6 +1,7 @@
 """Every dense contraction of one G+D step at config 2 (64x64 RGB, batch 64), each distinct geometry timed in isolation
 (forward / input gradient / weight gradient through the C ABI, HIP events) and set against two floors: the matrix pipe
-(six bf16 MFMAs per multiply-add: 2500 / 6 TFLOP/s nominal) and HBM (activations once each + the weight planes, 8 TB/s).
+(three fp16 MFMAs per multiply-add, 2500 / 3 TFLOP/s nominal, for layers of >= ops.F16_MIN_FLOPS; six bf16 MFMAs below) and HBM
+(activations once each + the weight planes, 8 TB/s).
 The table is sorted by the time a geometry costs per step; `x floor` says how far each launch is from the larger floor -
 the launches that are far from both are latency- / occupancy-bound and are what the tile and split heuristics can still move.
 Usage (GPU box): python tools/layer_table.py [--reps 20] [--top 40]"""
@@ -30,10 +31,10 @@ def collect(cfg, batch, dev):
     calls = collections.Counter()
     orig = ops._conv_apply
 
-    def spy(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision=0):
+    def spy(x, w, owner, spec, *rest, **kw):
         if spec.mode == "dense":
             calls[(spec.kind, spec.kh, spec.kw, spec.stride, spec.pad_h, spec.pad_w, tuple(x.shape), tuple(w.shape))] += 1
-        return orig(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision)
+        return orig(x, w, owner, spec, *rest, **kw)
     ops._conv_apply = spy
     try:
         step(*args)
@@ -57,8 +58,14 @@ def main():
     for (kind, kh, kw, s, ph, pw, xs, ws), n in calls.items():
         B, cin, H, W = xs
         cout = ws[0] if kind == "conv" else ws[1]
-        ms, flops, nbytes = bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, args.reps)
-        floor = max(flops / (2500e12 / 6), nbytes / 8e12) * 1e3          # ms
+        # the form the step runs the layer in: two fp16 pieces (three MFMAs per multiply-add) from ops.F16_MIN_FLOPS of work up -
+        # where the operands' largest magnitudes are known, which this table assumes -, three bf16 pieces (six) below
+        oh = (H + 2 * ph - kh) // s + 1 if kind == "conv" else H
+        ow = (W + 2 * pw - kw) // s + 1 if kind == "conv" else W
+        work = 2.0 * B * oh * ow * cin * cout * kh * kw
+        f16 = work >= ops.F16_MIN_FLOPS
+        ms, flops, nbytes = bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, args.reps, 2 if f16 else 0)
+        floor = max(flops / (2500e12 / (3 if f16 else 6)), nbytes / 8e12) * 1e3          # ms
         rows.append((n * sum(ms), n, kind, cin, cout, kh, kw, s, B, H, W, ms, flops, floor))
     rows.sort(reverse=True)
     total = sum(r[0] for r in rows)
