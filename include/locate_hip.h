@@ -257,7 +257,7 @@ int locate_multi_copy(const void* tensors, const void* chunks, int n_chunks, int
 size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */
 int locate_nadam_chunk_elems(void);
 int locate_nadam_step(const void* tensors, void* coef, const void* chunks, int n_tensors, int n_chunks, double lr, double beta1,
-                      double beta2, double eps, double schedule_decay, void* stream);
+                      double beta2, double eps, double schedule_decay, double weight_decay, void* stream);
 
 /* ---- loss glue (main.py:149-156,164-169, libs/utils.py:133-134, libs/grad_penalty.py:1-2): values and the
  *      gradients w.r.t. the discriminator outputs ---- */

@@ -99,7 +99,7 @@ PROTOTYPES = {
     "locate_multi_copy": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p]),
     "locate_nadam_tensor_record_bytes": (c_sz, []),
     "locate_nadam_chunk_elems": (c_i, []),
-    "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_p]),
+    "locate_nadam_step": (c_i, [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_d, c_p]),
     "locate_d_loss": (c_i, [c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     "locate_g_loss": (c_i, [c_p, c_i, c_p, c_p, c_p]),
 }

@@ -7,6 +7,7 @@
 //   t <- t + 1
 //   mc_t   = b1 (1 - 0.5 * 0.96^(t sd)),  mc_t1 = b1 (1 - 0.5 * 0.96^((t+1) sd))
 //   ms_new = m_schedule * mc_t,  ms_next = ms_new * mc_t1,  m_schedule <- ms_new
+//   g <- g + weight_decay p   (nadam.py:65-66; 0 in the reference's training loop)
 //   m <- b1 m + (1-b1) g ;  v <- b2 v + (1-b2) g^2 ;  denom = sqrt(v / (1 - b2^t)) + eps
 //   p <- p - lr (1-mc_t)/(1-ms_new) * g / denom ;  p <- p - lr mc_t1/(1-ms_next) * m / denom
 #include "common.h"
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(64) nadam_schedule_kernel(const NadamTensor* _
 
 __global__ void __launch_bounds__(256) nadam_update_kernel(const NadamTensor* __restrict__ tensors,
                                                            const NadamCoef* __restrict__ coef,
-                                                           const int2* __restrict__ chunks, float b1, float b2, float eps) {
+                                                           const int2* __restrict__ chunks, float b1, float b2, float eps, float wd) {
     const int2 ch = chunks[blockIdx.x];
     const NadamTensor T = tensors[ch.x];
     const NadamCoef c = coef[ch.x];
@@ -58,13 +59,13 @@ __global__ void __launch_bounds__(256) nadam_update_kernel(const NadamTensor* __
     if (end > T.n) end = T.n;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        const float g = T.g[i];
+        float p = T.p[i];
+        const float g = wd != 0.0f ? fmaf(wd, p, T.g[i]) : T.g[i];          // nadam.py:65-66: grad + weight_decay * p
         float m = T.m[i] * b1;
         m = m + omb1 * g;
         float v = T.v[i] * b2;
         v = v + omb2 * g * g;
         const float denom = sqrtf(v / c.bias2) + eps;
-        float p = T.p[i];
         p = p + c.c_grad * (g / denom);
         p = p + c.c_mom * (m / denom);
         T.m[i] = m;
@@ -80,7 +81,7 @@ LOCATE_API int locate_nadam_chunk_elems(void) { return NADAM_CHUNK; }
 // chunks: DEVICE array of n_chunks (tensor index, chunk index) int pairs covering every tensor in
 // locate_nadam_chunk_elems() pieces.
 LOCATE_API int locate_nadam_step(const void* tensors, void* coef, const void* chunks, int n_tensors, int n_chunks, double lr,
-                                 double beta1, double beta2, double eps, double schedule_decay, void* stream) {
+                                 double beta1, double beta2, double eps, double schedule_decay, double weight_decay, void* stream) {
     LOCATE_REQUIRE(tensors && coef && chunks && n_tensors > 0 && n_chunks > 0, "locate_nadam_step: bad arguments");
     hipStream_t st = as_stream(stream);
     nadam_schedule_kernel<<<(n_tensors + 63) / 64, 64, 0, st>>>(static_cast<const NadamTensor*>(tensors),
@@ -88,7 +89,8 @@ LOCATE_API int locate_nadam_step(const void* tensors, void* coef, const void* ch
                                                                schedule_decay);
     LOCATE_LAUNCH_CHECK("locate_nadam_step(schedule)");
     nadam_update_kernel<<<n_chunks, 256, 0, st>>>(static_cast<const NadamTensor*>(tensors), static_cast<const NadamCoef*>(coef),
-                                                  static_cast<const int2*>(chunks), (float)beta1, (float)beta2, (float)eps);
+                                                  static_cast<const int2*>(chunks), (float)beta1, (float)beta2, (float)eps,
+                                                  (float)weight_decay);
     LOCATE_LAUNCH_CHECK("locate_nadam_step(update)");
     return LOCATE_OK;
 }

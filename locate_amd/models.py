@@ -32,6 +32,10 @@ class SpectralNormBatch:
 
     def __init__(self, model):
         self.layers = [m for m in model.modules() if isinstance(m, SpectralNorm)]
+        rounds = {m.power_iterations for m in self.layers}
+        if len(rounds) > 1:
+            raise NotImplementedError("the batched spectral norm advances all layers together: one power_iterations value per network")
+        self.rounds = rounds.pop() if rounds else 1
         self._key = None
         self._tables = None
         self._meta = None
@@ -106,8 +110,9 @@ class SpectralNormBatch:
             r = self._next
             self._next = (r + 1) % self.RING
             self._gen[r] += 1
-            check(lib().locate_sn_power_iter_batched(self._tables[r].data_ptr(), len(self.layers), self.max_h, self.max_wd,
-                                                     torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
+            for _ in range(self.rounds):            # power_iterations rounds into the same set: its sigma is the last round's
+                check(lib().locate_sn_power_iter_batched(self._tables[r].data_ptr(), len(self.layers), self.max_h, self.max_wd,
+                                                         torch.cuda.current_stream().cuda_stream), "locate_sn_power_iter_batched")
             out.append((r, self._gen[r]))
         return out
 

@@ -81,8 +81,8 @@ class SpectralNorm(_Bound):
 
     def __init__(self, module, name="weight", power_iterations=1):
         super().__init__()
-        if power_iterations != 1:
-            raise NotImplementedError("power_iterations = 1 is the only value the reference uses")
+        if int(power_iterations) < 1:
+            raise ValueError("power_iterations must be >= 1")          # (the reference's loop would leave sigma from stale u, v)
         self.module = module
         self.name = name
         self.power_iterations = power_iterations
@@ -156,7 +156,8 @@ class SpectralNorm(_Bound):
         m = self.module
         pre, self._pre = self._pre, None
         if pre is None:
-            pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
+            for _ in range(self.power_iterations):       # spectral_norm.py:26-29: u, v advance every round, sigma from the last
+                pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
         return tuple(pre) + (None,) * (3 - len(pre))
 
     def forward(self, x, out=None):

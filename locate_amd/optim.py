@@ -12,8 +12,8 @@ from ._lib import check, lib
 
 class Nadam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, schedule_decay=4e-3):
-        if weight_decay != 0:
-            raise NotImplementedError("weight_decay is never used by the reference training loop")
+        if weight_decay < 0:
+            raise ValueError("weight_decay must be >= 0")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, schedule_decay=schedule_decay)
         super().__init__(params, defaults)
         self._tables = {}
@@ -108,6 +108,7 @@ class Nadam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             check(lib().locate_nadam_step(t_dev.data_ptr(), coef.data_ptr(), c_dev.data_ptr(), n_t, n_c, float(group["lr"]),
                                           float(b1), float(b2), float(group["eps"]), float(group["schedule_decay"]),
+                                          float(group["weight_decay"]),
                                           torch.cuda.current_stream().cuda_stream), "locate_nadam_step")
             # the kernel writes through raw pointers: tell autograd / the packed-panel cache that the weights changed
             torch._C._increment_version(plist)

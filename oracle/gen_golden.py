@@ -477,6 +477,56 @@ def _gen_step_record(name, S, B, ff, **consts):
     _save(name, d)
 
 
+def gen_branches():
+    """G21: the two branches of the reference the shipped training loop never takes ("small refusals"):
+    Nadam with weight_decay != 0 (libs/nadam.py:65-66) and SpectralNorm(power_iterations > 1) (libs/spectral_norm.py:26-29)."""
+    import warnings
+    import torch
+    from ref_loader import load_reference
+    ns = load_reference(32, 1)
+    warnings.simplefilter("ignore")
+    torch.manual_seed(2121)
+    d = {}
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    opt = ns.nadam.Nadam(ps, lr=ns.config.DLR, betas=(ns.config.BETA_1, ns.config.BETA_2), weight_decay=0.05)
+    for i, p in enumerate(ps):
+        d["wd/p%d_0" % i] = _np(p)
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            p.grad = torch.randn_like(p)
+            d["wd/g%d_%d" % (i, step)] = _np(p.grad)
+        opt.step()
+        for i, p in enumerate(ps):
+            d["wd/p%d_%d" % (i, step)] = _np(p)
+    d["wd/lr"] = np.float64(ns.config.DLR)
+    d["wd/betas"] = np.array([ns.config.BETA_1, ns.config.BETA_2], np.float64)
+    d["wd/weight_decay"] = np.float64(0.05)
+    SN = ns.spectral_norm.SpectralNorm
+    for name, inner, xshape, iters in (("conv3", torch.nn.Conv2d(5, 3, 3, stride=1, padding=1, bias=False), (2, 5, 6, 6), 3),
+                                        ("convT4s2", torch.nn.ConvTranspose2d(6, 6, 4, stride=2, padding=1, bias=False), (2, 6, 4, 4), 2)):
+        mod = SN(inner, power_iterations=iters)
+        mod.requires_grad_(True)
+        tag = "pi/" + name
+        d[tag + "/iters"] = np.int64(iters)
+        _sd(tag + "/sd0/", mod, d)
+        x = torch.randn(*xshape, requires_grad=True)
+        d[tag + "/x"] = _np(x)
+        outs, gs = [], []
+        for k in range(2):
+            y = mod(x)
+            outs.append(y)
+            d[tag + "/y%d" % k] = _np(y)
+            d[tag + "/u%d" % k] = _np(mod.module.weight_u)
+            d[tag + "/v%d" % k] = _np(mod.module.weight_v)
+            gk = torch.randn_like(y)
+            gs.append(gk)
+            d[tag + "/g%d" % k] = _np(gk)
+        sum((o * gg).sum() for o, gg in zip(outs, gs)).backward()
+        d[tag + "/dx"] = _np(x.grad)
+        _grads(tag + "/grad/", mod, d)
+    _save("g21_branches", d)
+
+
 def gen_f64():
     """The reference's own fp32 rounding noise on the ill-conditioned scalars of a step, per configuration: the same seeded
     build and the same inputs run twice through the REFERENCE, once as shipped (fp32) and once with both networks converted
@@ -529,7 +579,7 @@ F64_RECORDS = {
 }
 
 
-GROUPS = {"f64": gen_f64, "ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
+GROUPS = {"f64": gen_f64, "branches": gen_branches, "ops": gen_ops, "tiny": gen_tiny, "init": gen_init, "config1": gen_config1, "config3": gen_config3,
           "config2": gen_config2, "size256": gen_size256, "size256_full": gen_size256_full, "variants": gen_variants}
 
 
@@ -538,7 +588,7 @@ def main(argv):
         GROUPS[argv[1]]()
         return
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    runs = [("ops", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {}), ("size256_full", {})]
+    runs = [("ops", {}), ("branches", {}), ("tiny", {}), ("config1", {}), ("config3", {}), ("config2", {}), ("size256", {}), ("size256_full", {})]
     runs += [("init", {"LOCATE_GOLDEN_INIT_CFG": c}) for c in ("tiny32", "full32", "full64")]
     runs += [("variants", {"LOCATE_GOLDEN_VARIANT": v}) for v in VARIANTS]
     runs += [("f64", {"LOCATE_GOLDEN_F64": v}) for v in F64_RECORDS]

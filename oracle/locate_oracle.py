@@ -183,14 +183,16 @@ class SigmaFn(torch.autograd.Function):
         return dw, du, dv
 
 
-def sn_weight(P, prefix):
-    """One power iteration (state update through .data, no graph) + normalised weight W_bar / sigma."""
+def sn_weight(P, prefix, power_iterations=1):
+    """`power_iterations` power iterations (spectral_norm.py:26-29; state update through .data, no graph; the networks use 1) +
+    normalised weight W_bar / sigma."""
     w, u, v = P[prefix + "weight_bar"], P[prefix + "weight_u"], P[prefix + "weight_v"]
     h = w.shape[0]
     with torch.no_grad():
         w2 = w.detach().reshape(h, -1)
-        v.data.copy_(_l2n(w2.t().mv(u.detach())))
-        u.data.copy_(_l2n(w2.mv(v.detach())))
+        for _ in range(power_iterations):
+            v.data.copy_(_l2n(w2.t().mv(u.detach())))
+            u.data.copy_(_l2n(w2.mv(v.detach())))
     sigma = SigmaFn.apply(w.reshape(h, -1), u, v)
     return w / sigma
 
@@ -374,8 +376,8 @@ def consistency_penalty(d_true, d_aug, gamma=100):
 class Nadam:
     """nadam.py:31-89 restated; per-tensor step / m_schedule (tensors whose grad was None skip the update)."""
 
-    def __init__(self, lr, betas, eps=1e-8, schedule_decay=4e-3):
-        self.lr, self.betas, self.eps, self.schedule_decay = lr, betas, eps, schedule_decay
+    def __init__(self, lr, betas, eps=1e-8, schedule_decay=4e-3, weight_decay=0.0):
+        self.lr, self.betas, self.eps, self.schedule_decay, self.weight_decay = lr, betas, eps, schedule_decay, weight_decay
         self.state = {}
 
     def step(self, P, grads):
@@ -387,6 +389,8 @@ class Nadam:
             st = self.state.setdefault(name, dict(step=0, m_schedule=1.0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
             st["step"] += 1
             t = st["step"]
+            if self.weight_decay != 0:                      # nadam.py:65-66
+                g = g.add(p.detach(), alpha=self.weight_decay)
             mc_t = b1 * (1.0 - 0.5 * 0.96 ** (t * self.schedule_decay))
             mc_t1 = b1 * (1.0 - 0.5 * 0.96 ** ((t + 1) * self.schedule_decay))
             ms_new = st["m_schedule"] * mc_t

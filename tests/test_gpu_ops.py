@@ -858,3 +858,41 @@ def test_upsample_kernel_variants_agree_bit_for_bit():
     odd[..., :16] = x
     y_odd = ops.upsample2x(odd)                                  # W = 17: the scalar kernel
     assert torch.equal(y_tile[..., :30], y_odd[..., :30])
+
+
+@pytest.mark.gpu
+def test_branches_the_training_loop_never_takes():
+    """Nadam with weight_decay and SpectralNorm(power_iterations > 1) on the MI355X against the reference's records (g21)."""
+    from locate_amd import Nadam, SpectralNorm
+    z = load_golden("g21_branches")
+    ps = [torch.nn.Parameter(G_(z["wd/p%d_0" % i]).clone()) for i in range(2)]
+    opt = Nadam(ps, lr=float(z["wd/lr"]), betas=tuple(float(b) for b in z["wd/betas"]), weight_decay=float(z["wd/weight_decay"]))
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            p.grad = G_(z["wd/g%d_%d" % (i, step)]).clone()
+        opt.step()
+        for i, p in enumerate(ps):
+            assert_close(p.detach().cpu(), z["wd/p%d_%d" % (i, step)], 2e-6, "p%d step %d" % (i, step))
+    nn = torch.nn
+    for name, inner in (("conv3", nn.Conv2d(5, 3, 3, stride=1, padding=1, bias=False)),
+                        ("convT4s2", nn.ConvTranspose2d(6, 6, 4, stride=2, padding=1, bias=False))):
+        tag = "pi/" + name
+        mod = SpectralNorm(inner, power_iterations=int(z[tag + "/iters"]))
+        mod.load_state_dict(sub(z, tag + "/sd0/"))
+        mod = mod.to(dev())
+        mod.requires_grad_(True)
+        x = G_(z[tag + "/x"]).requires_grad_(True)
+        outs = []
+        for k in range(2):
+            y = mod(x)
+            outs.append(y)
+            assert_close(y.cpu(), z[tag + "/y%d" % k], 2e-5, name + " y%d" % k)
+            assert_close(mod.module.weight_u.cpu(), z[tag + "/u%d" % k], 1e-5, name + " u%d" % k)
+            assert_close(mod.module.weight_v.cpu(), z[tag + "/v%d" % k], 1e-5, name + " v%d" % k)
+        sum((o * G_(z[tag + "/g%d" % k])).sum() for k, o in enumerate(outs)).backward()
+        assert_close(x.grad.cpu(), z[tag + "/dx"], 3e-5, name + " dx")
+        want = sub(z, tag + "/grad/")
+        got = {k: p.grad.cpu() for k, p in mod.named_parameters() if p.grad is not None}
+        assert set(got) == set(want)
+        for k in want:
+            assert_close(got[k], want[k], 5e-4 if k.endswith(("weight_u", "weight_v")) else 1e-4, name + " " + k)

@@ -5,6 +5,7 @@ gradients 1e-4, normalised max error."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import assert_close, load_golden
 from oracle import locate_oracle as O
@@ -309,3 +310,32 @@ def test_float64_reference_records_are_the_same_run(name):
         np.testing.assert_allclose(z64["f32/%s/post_norms" % tag], z[tag + "/post_norms"], rtol=1e-12)
         a, b = z64["f32/%s/grad_norms" % tag], z64["f64/%s/grad_norms" % tag]
         assert float(np.max(np.abs(a - b)) / np.max(b)) <= 1e-4, tag
+
+
+def test_g21_branches_the_training_loop_never_takes():
+    """Nadam with weight_decay (nadam.py:65-66) and SpectralNorm(power_iterations > 1) (spectral_norm.py:26-29) against records
+    taken from the reference (oracle/gen_golden.py branches)."""
+    z = load_golden("g21_branches")
+    P = {"p%d" % i: T(z["wd/p%d_0" % i]).clone() for i in range(2)}
+    opt = O.Nadam(float(z["wd/lr"]), tuple(z["wd/betas"]), weight_decay=float(z["wd/weight_decay"]))
+    for step in range(1, 4):
+        opt.step(P, {"p%d" % i: T(z["wd/g%d_%d" % (i, step)]) for i in range(2)})
+        for i in range(2):
+            assert_close(P["p%d" % i], z["wd/p%d_%d" % (i, step)], 2e-6, "p%d step %d" % (i, step))
+    for name, kind, stride, pad in (("conv3", "conv", 1, 1), ("convT4s2", "convT", 2, 1)):
+        tag = "pi/" + name
+        iters = int(z[tag + "/iters"])
+        P = O.make_params({k[len(tag + "/sd0/"):]: T(z[k]) for k in z.files if k.startswith(tag + "/sd0/")}, trainable_uv=True)
+        x = T(z[tag + "/x"]).clone().requires_grad_(True)
+        outs = []
+        for k in range(2):
+            w = O.sn_weight(P, "module.", power_iterations=iters)
+            y = F.conv2d(x, w, None, stride, pad) if kind == "conv" else F.conv_transpose2d(x, w, None, stride, pad)
+            outs.append(y)
+            assert_close(y, z[tag + "/y%d" % k], 1e-5, name + " y%d" % k)
+            assert_close(P["module.weight_u"], z[tag + "/u%d" % k], 1e-6, name + " u%d" % k)
+        sum((o * T(z[tag + "/g%d" % k])).sum() for k, o in enumerate(outs)).backward()
+        assert_close(x.grad, z[tag + "/dx"], 2e-5, name + " dx")
+        for k in z.files:
+            if k.startswith(tag + "/grad/"):
+                assert_close(P[k[len(tag + "/grad/"):]].grad, z[k], 5e-4 if k.endswith(("weight_u", "weight_v")) else 5e-5, k)
