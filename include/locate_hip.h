@@ -72,6 +72,16 @@ int locate_norm_bwd(const float* x, const float* g, const float* stats, const fl
                     const float* bias, int with_act, float* dx, float* dscale, float* dbias, int B, int C, int hw, int groups,
                     void* workspace, int accumulate_dx, void* stream);
 /* out[c] = sum over batch and space of g[b, c, :] (bias gradients: libs/scale.py:28-34, libs/linear.py:10) */
+/* the same backward in TWO launches (no middle launch in the pass's dependent chain): dx and - with scale_per_sample - the
+ * per-sample scale gradient; the per-channel dscale[c] / dbias[c] (parameter gradients) come from locate_fin_norm_channels at
+ * the end of the pass, out of the plane sums S1, S2 this call leaves in its workspace at locate_norm_bwd_fused_plane_offset()
+ * (S1 [B*C] floats, then S2): records p = {S1, S2, stats, dscale [C] | 0, dbias [C] | 0}, i = {B, C, groups} */
+size_t locate_norm_bwd_fused_workspace_bytes(int B, int C);
+size_t locate_norm_bwd_fused_plane_offset(void);
+int locate_norm_bwd_fused(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample,
+                          const float* bias, int with_act, float* dx, float* dscale_sample, int B, int C, int hw, int groups,
+                          void* workspace, int accumulate_dx, void* stream);
+int locate_fin_norm_channels(const void* records, int n, void* stream);
 size_t locate_channel_sum_workspace_bytes(int B, int C, int hw);
 int locate_channel_sum(const float* g, float* out, int B, int C, int hw, int64_t batch_stride, void* workspace, void* stream);
 

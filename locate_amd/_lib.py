@@ -40,6 +40,10 @@ PROTOTYPES = {
     "locate_norm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
     "locate_norm_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "locate_norm_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "locate_norm_bwd_fused_workspace_bytes": (c_sz, [c_i, c_i]),
+    "locate_norm_bwd_fused_plane_offset": (c_sz, []),
+    "locate_norm_bwd_fused": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "locate_fin_norm_channels": (c_i, [c_p, c_i, c_p]),
     "locate_channel_sum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "locate_channel_sum": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_p, c_p]),
     "locate_gate_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),

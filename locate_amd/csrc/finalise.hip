@@ -12,16 +12,7 @@
 // kernels (spectral.hip, elementwise.hip): results are bit-identical to the unbatched path, which the data-parallel eager
 // mode still takes (its reducer hooks need complete gradients from autograd).
 #include "common.h"
-
-#define FIN_MAX 32
-struct FinRec {
-    const void* p[8];
-    long long l[2];
-    int i[8];
-};
-struct FinBatch {
-    FinRec r[FIN_MAX];
-};
+#include "finrec.h"
 
 LOCATE_API size_t locate_fin_record_bytes(void) { return sizeof(FinRec); }
 

@@ -10,6 +10,7 @@
 // then per group (what three separate reference forwards compute), parameter gradients sum over all groups.
 // All HBM-bound.  Statistics are accumulated in fp64 in a fixed order (no atomics: bit-reproducible).
 #include "common.h"
+#include "finrec.h"
 
 #define NORM_MAX_PARTIALS 512
 #define NORM_MAX_GROUPS 4
@@ -201,7 +202,15 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
                                                              const float* __restrict__ stats, const float* __restrict__ scale,
                                                              int scale_per_sample, const float* __restrict__ bias, int C,
                                                              float* __restrict__ S1, float* __restrict__ S2, int64_t planes,
-                                                             int64_t planes_g, int hw) {
+                                                             int64_t planes_g, int hw, double* __restrict__ block_partial,
+                                                             float* __restrict__ dscale_sample) {
+    // block_partial (two-launch form, locate_norm_bwd_fused): this block's share of sum_p y[p] S1[p] and sum_p y[p] S2[p] per
+    // group, [block][NORM_MAX_GROUPS][2] doubles - the dx kernel adds the blocks up itself, the middle launch is gone;
+    // dscale_sample: the per-sample scale gradient S2[p] / std straight from here
+    __shared__ double bp[4][NORM_MAX_GROUPS][2];
+    double acc_a[NORM_MAX_GROUPS], acc_b[NORM_MAX_GROUPS];
+#pragma unroll
+    for (int q = 0; q < NORM_MAX_GROUPS; ++q) acc_a[q] = acc_b[q] = 0.0;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -236,6 +245,28 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
         if (lane == 0) {
             S1[p] = s1;
             S2[p] = s2;
+            if (block_partial) {
+                const float yv = scale[scale_per_sample ? p : c];
+#pragma unroll
+                for (int q = 0; q < NORM_MAX_GROUPS; ++q)
+                    if (q == grp) {
+                        acc_a[q] += (double)yv * (double)s1;
+                        acc_b[q] += (double)yv * (double)s2;
+                    }
+                if (dscale_sample) dscale_sample[p] = s2 / stats[2 * grp + 1];
+            }
+        }
+    }
+    if (block_partial) {          // the four waves' lane-0 sums in wave order
+        const int wid = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NORM_MAX_GROUPS; ++q) { bp[wid][q][0] = acc_a[q]; bp[wid][q][1] = acc_b[q]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < NORM_MAX_GROUPS * 2) {
+            const int q = threadIdx.x >> 1, e = threadIdx.x & 1;
+            block_partial[((int64_t)blockIdx.x * NORM_MAX_GROUPS + q) * 2 + e] = ((bp[0][q][e] + bp[1][q][e]) + bp[2][q][e]) + bp[3][q][e];
         }
     }
 }
@@ -387,9 +418,9 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = as_stream(stream);
     if (with_act)
-        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw);
+        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr);
     else
-        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw);
+        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(plane)");
     norm_bwd_final_kernel<<<nfb, 256, 0, st>>>(S1, S2, stats, scale, scale_per_sample, dscale, dbias, partial, B, C, groups);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(final)");
@@ -399,6 +430,112 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     else
         norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, nfb, dx, planes_g, C, hw, accumulate_dx);
     LOCATE_LAUNCH_CHECK("locate_norm_bwd(dx)");
+    return LOCATE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-launch backward (round 3): the plane kernel also leaves, per block, its share of the two group sums the dx kernel
+// needs (and the per-sample scale gradient), so the launch between them is gone from the pass's dependent chain.  What that
+// launch also produced - dbias[c] and the per-channel dscale[c], PARAMETER gradients - is computed for all norms of a
+// backward pass at its end (locate_fin_norm_channels) from the plane sums S1 / S2, which stay in the workspace.
+//   workspace: [NBF_BLOCKS][NORM_MAX_GROUPS][2] doubles, then S1 [B*C], S2 [B*C] floats
+// ---------------------------------------------------------------------------------------------
+#define NBF_BLOCKS 512
+LOCATE_API size_t locate_norm_bwd_fused_workspace_bytes(int B, int C) {
+    return (size_t)NBF_BLOCKS * NORM_MAX_GROUPS * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
+}
+// byte offset of S1 inside that workspace (S2 follows after B*C floats)
+LOCATE_API size_t locate_norm_bwd_fused_plane_offset(void) { return (size_t)NBF_BLOCKS * NORM_MAX_GROUPS * 2 * sizeof(double); }
+
+// dscale_sample: [B*C] when scale_per_sample (written), else must be null (the per-channel dscale comes from the finaliser)
+LOCATE_API int locate_norm_bwd_fused(const float* x, const float* g, const float* stats, const float* scale, int scale_per_sample,
+                                     const float* bias, int with_act, float* dx, float* dscale_sample, int B, int C, int hw,
+                                     int groups, void* workspace, int accumulate_dx, void* stream) {
+    LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && workspace, "locate_norm_bwd_fused: bad shape or missing workspace");
+    LOCATE_REQUIRE(groups >= 1 && groups <= NORM_MAX_GROUPS && B % groups == 0, "locate_norm_bwd_fused: bad group count");
+    LOCATE_REQUIRE(!with_act || bias, "locate_norm_bwd_fused: with_act needs the bias");
+    LOCATE_REQUIRE(!scale_per_sample == !dscale_sample, "locate_norm_bwd_fused: dscale_sample goes with scale_per_sample");
+    LOCATE_REQUIRE((int64_t)B * C / groups * hw < (1ll << 33), "locate_norm_bwd_fused: more than 2^33 elements per group");
+    const int64_t planes = (int64_t)B * C, planes_g = planes / groups;
+    LOCATE_REQUIRE(groups == 1 || ((planes_g * hw) & 3) == 0, "locate_norm_bwd_fused: grouped tensors need a group size that is a multiple of 4");
+    double* partial = static_cast<double*>(workspace);
+    float* S1 = reinterpret_cast<float*>(partial + (size_t)NBF_BLOCKS * NORM_MAX_GROUPS * 2);
+    float* S2 = S1 + planes;
+    int64_t blocks = cdiv64(planes, 4);
+    if (blocks > NBF_BLOCKS) blocks = NBF_BLOCKS;
+    hipStream_t st = as_stream(stream);
+    if (with_act)
+        norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample);
+    else
+        norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample);
+    LOCATE_LAUNCH_CHECK("locate_norm_bwd_fused(plane)");
+    const dim3 grid(stream_grid(planes_g * hw, 1024), groups);
+    if (with_act)
+        norm_bwd_dx_kernel<true><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, (int)blocks, dx, planes_g, C, hw, accumulate_dx);
+    else
+        norm_bwd_dx_kernel<false><<<grid, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, partial, (int)blocks, dx, planes_g, C, hw, accumulate_dx);
+    LOCATE_LAUNCH_CHECK("locate_norm_bwd_fused(dx)");
+    return LOCATE_OK;
+}
+
+// dbias[c] = sum_b S1[b, c];  dscale[c] = sum_b S2[b, c] / std(group of b)   - norm_bwd_final_kernel's arithmetic (16 channels x
+// 16 batch slots per block, slots added in order), for all norms of a pass in one launch.
+// records: p0 S1, p1 S2, p2 stats, p3 dscale [C] | 0, p4 dbias [C];  i0 B, i1 C, i2 groups, i5 first block, i6 block count
+__global__ void __launch_bounds__(256) fin_norm_channels_kernel(const FinBatch batch, int n_rec) {
+    __shared__ float part_b[256], part_y[256];
+    int ri = 0;
+    for (int k = 1; k < n_rec; ++k)
+        if ((int)blockIdx.x >= batch.r[k].i[5]) ri = k;
+    const FinRec& R = batch.r[ri];
+    const int bx = (int)blockIdx.x - R.i[5];
+    const float* __restrict__ S1 = static_cast<const float*>(R.p[0]);
+    const float* __restrict__ S2 = static_cast<const float*>(R.p[1]);
+    const float* __restrict__ stats = static_cast<const float*>(R.p[2]);
+    float* __restrict__ dscale = static_cast<float*>(const_cast<void*>(R.p[3]));
+    float* __restrict__ dbias = static_cast<float*>(const_cast<void*>(R.p[4]));
+    const int B = R.i[0], C = R.i[1], groups = R.i[2];
+    const int Bg = B / groups;
+    const int cl = threadIdx.x & (NF_CH - 1), slot = threadIdx.x / NF_CH;
+    const int c = bx * NF_CH + cl;
+    float db = 0.0f, dy = 0.0f;
+    if (c < C) {
+        for (int b = slot; b < B; b += NF_SLOTS) {
+            const float sf = stats[2 * (b / Bg) + 1];
+            const int64_t p = (int64_t)b * C + c;
+            db += S1[p];
+            dy += S2[p] / sf;
+        }
+    }
+    part_b[threadIdx.x] = db;
+    part_y[threadIdx.x] = dy;
+    __syncthreads();
+    if (slot == 0 && c < C) {
+        float tb = 0.0f, ty = 0.0f;
+        for (int s2 = 0; s2 < NF_SLOTS; ++s2) { tb += part_b[s2 * NF_CH + cl]; ty += part_y[s2 * NF_CH + cl]; }
+        if (dbias) dbias[c] = tb;
+        if (dscale) dscale[c] = ty;
+    }
+}
+
+LOCATE_API int locate_fin_norm_channels(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0, "locate_fin_norm_channels: bad arguments");
+    const FinRec* rec = static_cast<const FinRec*>(records);
+    for (int at = 0; at < n; at += FIN_MAX) {
+        FinBatch b = {};
+        const int m = n - at < FIN_MAX ? n - at : FIN_MAX;
+        int blocks = 0;
+        for (int k = 0; k < m; ++k) {
+            b.r[k] = rec[at + k];
+            FinRec& R = b.r[k];
+            LOCATE_REQUIRE(R.p[0] && R.p[1] && R.p[2] && (R.p[3] || R.p[4]) && R.i[0] > 0 && R.i[1] > 0 && R.i[2] >= 1 &&
+                           R.i[2] <= NORM_MAX_GROUPS && R.i[0] % R.i[2] == 0, "locate_fin_norm_channels: bad record %d", at + k);
+            R.i[5] = blocks;
+            R.i[6] = (R.i[1] + NF_CH - 1) / NF_CH;
+            blocks += R.i[6];
+        }
+        fin_norm_channels_kernel<<<blocks, 256, 0, as_stream(stream)>>>(b, m);
+        LOCATE_LAUNCH_CHECK("locate_fin_norm_channels");
+    }
     return LOCATE_OK;
 }
 

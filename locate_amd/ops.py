@@ -251,6 +251,7 @@ class Runtime:
         self._fin_rank1 = []
         self._fin_sums = []
         self._fin_chan = []
+        self._fin_norm = []
         self._streams = {}               # streams on which this pass queued deferred work / produced late gradients
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
@@ -278,7 +279,7 @@ class Runtime:
         self._keep = []
         self._streams = {}
         AMAX.new_pass()
-        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan = [], [], [], []
+        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan, self._fin_norm = [], [], [], [], []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
         self._dv_layers = {}
@@ -311,11 +312,12 @@ class Runtime:
         for queue, fn, name in ((self._fin_dots, L.locate_fin_sn_dots, "locate_fin_sn_dots"),
                                 (self._fin_rank1, L.locate_fin_sn_rank1, "locate_fin_sn_rank1"),
                                 (self._fin_sums, L.locate_fin_sums, "locate_fin_sums"),
-                                (self._fin_chan, L.locate_fin_channel_sums, "locate_fin_channel_sums")):
+                                (self._fin_chan, L.locate_fin_channel_sums, "locate_fin_channel_sums"),
+                                (self._fin_norm, L.locate_fin_norm_channels, "locate_fin_norm_channels")):
             if queue:
                 blob = b"".join(queue)
                 check(fn(blob, len(queue), st), name)
-        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan = [], [], [], []
+        self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan, self._fin_norm = [], [], [], [], []
         results, self._side_results = self._side_results, []
         self._keep = []
         for param, grad in results:
@@ -355,6 +357,13 @@ class Runtime:
         part = torch.empty(slices * Cn, dtype=torch.float32, device=g.device) if slices > 1 else None
         self._fin_chan.append(self._rec([g, out, part], [g.stride(0)], [Bn, Cn, hw]))
         self._keep.append((g, out, part))
+        self._schedule_end()
+
+    def queue_norm_channels(self, ws, plane_offset, planes, stats, dscale, dbias, B, C, groups):
+        """dscale[c] / dbias[c] of one InPlaceNorm out of the plane sums its two-launch backward left in `ws`."""
+        s1 = ws.data_ptr() + plane_offset
+        self._fin_norm.append(self._rec([s1, s1 + 4 * planes, stats, dscale, dbias], [], [B, C, groups]))
+        self._keep.append((ws, stats, dscale, dbias))
         self._schedule_end()
 
     def late_grad(self, param, grad):
@@ -561,8 +570,10 @@ class InPlaceNormFn(torch.autograd.Function):
     returns RootTanh(out) instead; the backward recomputes out on the fly, nothing but x is kept."""
 
     @staticmethod
-    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None, slot=None, amax=None):
+    def forward(ctx, x, scale, bias, with_act, groups, pre_partial=None, slot=None, amax=None, rt=None):
         ctx.slot = slot
+        ctx.rt = rt or DEFAULT_RUNTIME
+        ctx.scale_in, ctx.bias_in = scale, bias            # the parameters themselves (late gradients are assigned to them)
         x = _c(x, "norm input")
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
@@ -593,12 +604,32 @@ class InPlaceNormFn(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // (B * C)
         dx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
+        rt = ctx.rt
+        need_scale, need_bias = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        # Two-launch form: dx (and the per-sample scale gradient) now; the per-channel sums dscale[c] / dbias[c] - parameter
+        # gradients - with all the other norms of the pass at its end (locate_fin_norm_channels).  Taken when those gradients
+        # go to leaf parameters (or are not wanted at all: a frozen discriminator).
+        per_channel_scale_ok = ctx.per_sample or not need_scale or ctx.scale_in.is_leaf
+        if rt.defer_finalisers and per_channel_scale_ok and (not need_bias or ctx.bias_in.is_leaf):
+            ws = _ws(L.locate_norm_bwd_fused_workspace_bytes(B, C), x.device)
+            dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device) if ctx.per_sample else None
+            check(L.locate_norm_bwd_fused(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
+                                          _p(dscale), B, C, hw, ctx.groups, _p(ws), acc, st), "locate_norm_bwd_fused")
+            late_scale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device) if (need_scale and not ctx.per_sample) else None
+            late_bias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device) if need_bias else None
+            if late_scale is not None or late_bias is not None:
+                rt.queue_norm_channels(ws, L.locate_norm_bwd_fused_plane_offset(), B * C, stats, late_scale, late_bias, B, C, ctx.groups)
+                if late_scale is not None:
+                    rt.late_grad(ctx.scale_in, late_scale)
+                if late_bias is not None:
+                    rt.late_grad(ctx.bias_in, late_bias)
+            return dx, dscale, None, None, None, None, None, None, None
         dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device)
         dbias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device)
         ws = _ws(L.locate_norm_bwd_workspace_bytes(B, C), x.device)
         check(L.locate_norm_bwd(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
                                 _p(dscale), _p(dbias), B, C, hw, ctx.groups, _p(ws), acc, st), "locate_norm_bwd")
-        return dx, dscale, dbias, None, None, None, None, None
+        return dx, dscale, dbias, None, None, None, None, None, None
 
 
 def inplace_norm(x, scale, bias, with_act=False, runtime=None):
@@ -609,7 +640,7 @@ def inplace_norm(x, scale, bias, with_act=False, runtime=None):
     # the output's largest magnitude for the fp16-piece form of the contraction that consumes it (a conv stage behind
     # norm + RootTanh, the position gate's first 1x1 conv behind a plain norm)
     amax = AMAX.slot(x.device) if x.numel() >= (1 << 16) else None
-    out = InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None, amax)
+    out = InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None, amax, runtime)
     if amax is not None:
         out._locate_amax = amax
     return out
