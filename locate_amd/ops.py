@@ -208,13 +208,9 @@ tanh = TanhFn.apply
 
 
 def act_cat(latent, pre):
-    """cat([latent, RootTanh(pre)], 1) alone (see act_cat_scale)."""
+    """cat([latent, RootTanh(pre)], 1) as a launch of its own: the fall-back of the style chain for a link whose linear does not
+    run through the 1x1-map kernel (which writes this concatenation itself, nn.LinearModule.pre_and_next_input)."""
     return ActCatFn.apply(latent, pre)[0]
-
-
-def act_cat_scale(latent, pre):
-    """(cat([latent, RootTanh(pre)], 1), pre as a [B, w, 1, 1] style scale) - use the returned scale INSTEAD of viewing pre."""
-    return ActCatFn.apply(latent, pre)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -896,3 +896,32 @@ def test_branches_the_training_loop_never_takes():
         assert set(got) == set(want)
         for k in want:
             assert_close(got[k], want[k], 5e-4 if k.endswith(("weight_u", "weight_v")) else 1e-4, name + " " + k)
+
+
+@pytest.mark.gpu
+def test_style_link_fused_equals_separate_launches():
+    """A style-chain link as ONE launch (linear + bias, its RootTanh and the latent columns in front: the next link's input,
+    nn.LinearModule.pre_and_next_input) against the same link as linear -> act_cat (two launches, ops.ActCatFn): identical
+    values forward, and the same gradients for the weight, the bias and the input when both outputs carry a gradient."""
+    from locate_amd import ops
+    from locate_amd.nn import LinearModule
+    torch.manual_seed(3)
+    lm = LinearModule(24, 40).to(dev())
+    lm2 = LinearModule(24, 40).to(dev())
+    lm2.load_state_dict(lm.state_dict())
+    latent = torch.randn(6, 8, device=dev())
+    x1 = torch.randn(6, 24, device=dev(), requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    pre1, nxt1 = lm.pre_and_next_input(x1, latent)
+    pre2 = lm2.pre_activation(x2)
+    nxt2 = ops.act_cat(latent, pre2)
+    assert nxt1.shape == (6, 8 + 40) and torch.equal(nxt1[:, :8], latent)
+    assert torch.equal(pre1, pre2)
+    assert_close(nxt1.cpu(), nxt2.detach().cpu(), 1e-6, "next input")
+    g_pre, g_nxt = torch.randn_like(pre1), torch.randn_like(nxt1)
+    torch.autograd.backward([pre1, nxt1], [g_pre, g_nxt])
+    torch.autograd.backward([pre2, nxt2], [g_pre, g_nxt])
+    assert_close(x1.grad.cpu(), x2.grad.cpu(), 1e-5, "dx")
+    for (k, a), (_, b) in zip(lm.named_parameters(), lm2.named_parameters()):
+        if a.grad is not None or b.grad is not None:
+            assert_close(a.grad.cpu(), b.grad.cpu(), 1e-5, k)
