@@ -45,6 +45,11 @@ int locate_act_cat_rows_fwd(const float* latent, const float* pre, float* out, i
 /* g_add (nullable, [rows, w] contiguous): added to the result - the gradient pre receives as a norm's style scale */
 int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_row_stride, const float* g_add, float* gpre, int rows, int w,
                         void* stream);
+/* out = (a + b) + c, each operand contiguous inside a batch element with its own batch stride (elements): the one-pass sum of
+ * the three gradients that meet at a discriminator block's input (libs/block.py:38-52, libs/scale.py:28-34: the conv branch's
+ * norm, the identity half of the concatenation, the skip branch's 1x1 conv) - the reference leaves two adds to autograd */
+int locate_add3(const float* a, int64_t a_bs, const float* b, int64_t b_bs, const float* c, int64_t c_bs, float* out, int batch,
+                int64_t per, void* stream);
 int locate_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int locate_tanh_bwd(const float* y, const float* gy, float* gx, int64_t n, void* stream);
 
@@ -202,6 +207,19 @@ int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
                       double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
                       void* stream);
+
+/* The weight gradients of ALL small-map layers of one backward pass in ONE launch: the style chain's linears
+ * (libs/linear.py:7-15, libs/block.py:112-127), the channel gates' squeeze convs, the discriminator's layers on 1x1 maps, its
+ * last 5x5 conv and its head (one output pixel) - in the reference ~19 separate autograd weight-gradient kernels per iteration.
+ * locate_wgrad_batch_record() writes the launch of locate_conv_wgrad for one layer into a host record (same argument meaning)
+ * and returns its block count, or 0 when the geometry is not such a layer (launch it with locate_conv_wgrad then);
+ * locate_wgrad_batch() runs up to locate_wgrad_batch_max() packed records; results are those of the single launches. */
+size_t locate_wgrad_batch_record_bytes(void);
+int locate_wgrad_batch_max(void);
+int locate_wgrad_batch_record(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
+                              const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
+                              double* inner_partial, void* record);
+int locate_wgrad_batch(const void* records, int n, void* stream);
 
 /* ---- grouped convolutions of the SEPARABLE switch (libs/config.py:53; replaces the torch.nn.Conv2d /
  *      ConvTranspose2d(groups = ...) forward + autograd backward under libs/conv.py:14-18 and libs/attention.py:15-21).

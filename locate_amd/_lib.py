@@ -31,7 +31,12 @@ PROTOTYPES = {
     "locate_roottanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "locate_act_cat_rows_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "locate_act_rows_bwd": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_p]),
+    "locate_add3": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i64, c_p]),
     "locate_absmax_words": (c_i, []),
+    "locate_wgrad_batch_record_bytes": (c_sz, []),
+    "locate_wgrad_batch_max": (c_i, []),
+    "locate_wgrad_batch_record": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "locate_wgrad_batch": (c_i, [c_p, c_i, c_p]),
     "locate_absmax": (c_i, [c_p, c_i64, c_p, c_p]),
     "locate_tanh_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "locate_tanh_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
@@ -115,7 +120,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 5
+EXPECTED_ABI = 6
 
 
 _lib = None

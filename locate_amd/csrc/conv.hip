@@ -2552,15 +2552,16 @@ struct OnePix {
 #define SKW_MT 8          // gradient rows per block
 #define SKW_NC 32         // batch rows per load batch
 
-__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
-                                                           long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
-                                                           const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
-                                                           double* __restrict__ partial, int N, int M, int C, OnePix op) {
+__device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
+                                                  long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
+                                                  const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
+                                                  double* __restrict__ partial, int N, int M, int C, const OnePix& op, int bx, int by,
+                                                  int grid_x) {
     __shared__ double scratch[16];
     __shared__ float red[4][SKW_MT][64];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int j = blockIdx.x * 64 + lane;
-    const int i0 = blockIdx.y * SKW_MT;
+    const int j = bx * 64 + lane;
+    const int i0 = by * SKW_MT;
     const bool jok = j < C;
     const float* __restrict__ xc = x + (jok ? j : 0);
     float acc[SKW_MT];
@@ -2618,7 +2619,7 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
         // code above wrote (disjoint addresses: no ordering needed).  A channel whose pixels straddle two blocks is zeroed by
         // the block that holds its pixel 0.
         const int H = op.hw / op.W, taps = op.KH * op.KW;
-        const int first_col = blockIdx.x * 64;
+        const int first_col = bx * 64;
         const int c_first = (first_col + op.hw - 1) / op.hw;
         int c_last = (first_col + 63) / op.hw;
         if (c_last > op.Cw - 1) c_last = op.Cw - 1;
@@ -2634,8 +2635,43 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
     }
     if (partial) {
         dot = block_sum<double>(dot, scratch);
-        if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = dot;
+        if (threadIdx.x == 0) partial[by * grid_x + bx] = dot;
     }
+}
+
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
+                                                           long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
+                                                           const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
+                                                           double* __restrict__ partial, int N, int M, int C, OnePix op) {
+    skinny_wgrad_body(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x, blockIdx.y,
+                      gridDim.x);
+}
+
+// The same for ALL such layers of one backward pass in ONE launch (the style chain's links, the channel gates' squeeze convs,
+// the discriminator's 1x1-map layers, its last 5x5 conv and its head): records by value in the kernel arguments like the other
+// end-of-pass finalisers (finalise.hip) - every one of these launches is a ten-microsecond walk over the batch rows by a
+// handful of blocks; together they fill the chip once.  Arithmetic and summation order per layer are those of the single
+// launch (same body, same block shape).
+struct SkwRec {
+    const float* x; const float* gy; float* gw; const float* w_ref; const float* inv_scale; double* partial;
+    long long x_bs, gy_bs;
+    int scale_bg, scale_stride, N, M, C, grid_x, block0;
+    OnePix op;
+};
+#define SKW_MAX 24
+struct SkwBatch {
+    SkwRec r[SKW_MAX];
+};
+
+__global__ void __launch_bounds__(256) skinny_wgrad_batch_kernel(const SkwBatch b, int n) {
+    int k = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)blockIdx.x >= b.r[i].block0) k = i;          // block0 ascending
+    const SkwRec& r = b.r[k];
+    const int local = (int)blockIdx.x - r.block0;
+    const int by = local / r.grid_x, bx = local - by * r.grid_x;
+    skinny_wgrad_body(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N, r.M, r.C, r.op,
+                      bx, by, r.grid_x);
 }
 
 static bool skinny_wgrad_ok(const ConvGeom& g) {
@@ -2679,6 +2715,50 @@ LOCATE_API int locate_conv_wgrad_partials(const int* geom) {
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
     return nsplit > 1 ? wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW, nsplit) : tiles;
+}
+
+// ---- the small weight gradients of a pass in one launch (SkwRec above) ----
+LOCATE_API size_t locate_wgrad_batch_record_bytes(void) { return sizeof(SkwRec); }
+LOCATE_API int locate_wgrad_batch_max(void) { return SKW_MAX; }
+// Fills `record` (locate_wgrad_batch_record_bytes() bytes, host memory) with the launch of locate_conv_wgrad for this geometry
+// and these operands and returns its number of blocks - or 0 when the geometry is not one of the small-map layers (1x1 maps,
+// one output pixel), which the caller then launches on its own.  Same argument meaning as locate_conv_wgrad.
+LOCATE_API int locate_wgrad_batch_record(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
+                                         const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
+                                         double* inner_partial, void* record) {
+    const ConvGeom g = make_geom(geom);
+    if (geom_check(g, "locate_wgrad_batch_record") || !record || !x || !gy || !gw) return 0;
+    if (inner_partial && !w_ref) return 0;
+    if (scale_group_batch < 0 || (scale_group_batch > 0 && (!inv_scale || g.B % scale_group_batch != 0 || g.B / scale_group_batch > 4 ||
+                                                            w_ref || inner_partial))) return 0;
+    const bool skinny = skinny_wgrad_ok(g), onepix = !skinny && onepix_wgrad_ok(g);
+    if (!skinny && !onepix) return 0;
+    const dim3 grid = skinny ? skinny_wgrad_grid(g) : onepix_wgrad_grid(g);
+    SkwRec r;
+    r.x = x; r.gy = gy; r.gw = gw; r.w_ref = w_ref; r.inv_scale = inv_scale; r.partial = inner_partial;
+    r.x_bs = x_bs; r.gy_bs = gy_bs;
+    r.scale_bg = scale_group_batch; r.scale_stride = scale_stride; r.N = g.B; r.M = g.M; r.C = skinny ? g.C : g.C * g.H * g.W;
+    r.grid_x = (int)grid.x; r.block0 = 0;
+    r.op = skinny ? OnePix{0, 0, 0, 0, 0, 0, 0} : OnePix{g.H * g.W, g.W, g.KH, g.KW, g.pad_h, g.pad_w, g.C};
+    memcpy(record, &r, sizeof(r));
+    return (int)(grid.x * grid.y);
+}
+// Launches n records (filled by locate_wgrad_batch_record, in host memory, packed) in one grid.
+LOCATE_API int locate_wgrad_batch(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0 && n <= SKW_MAX, "locate_wgrad_batch: 1 .. locate_wgrad_batch_max() records");
+    SkwBatch b;
+    memcpy(b.r, records, (size_t)n * sizeof(SkwRec));
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const SkwRec& r = b.r[i];
+        LOCATE_REQUIRE(r.x && r.gy && r.gw && r.grid_x > 0 && r.M > 0 && r.C > 0 && r.N > 0, "locate_wgrad_batch: bad record");
+        b.r[i].block0 = (int)blocks;
+        blocks += (long long)r.grid_x * ((r.M + SKW_MT - 1) / SKW_MT);
+    }
+    LOCATE_REQUIRE(blocks < (1ll << 31), "locate_wgrad_batch: too many blocks");
+    skinny_wgrad_batch_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(b, n);
+    LOCATE_LAUNCH_CHECK("locate_wgrad_batch");
+    return LOCATE_OK;
 }
 
 // gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw]          (overwritten)

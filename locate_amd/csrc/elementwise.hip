@@ -138,6 +138,49 @@ LOCATE_API int locate_act_rows_bwd(const float* pre, const float* g, int64_t g_r
     return LOCATE_OK;
 }
 
+// out[b][i] = (a[b][i] + b_[b][i]) + c[b][i]: the three gradients that meet at a tensor with three consumers (the discriminator
+// block's input: norm of the conv branch, identity half of the concatenation, the skip branch's 1x1 conv), in ONE pass and in a
+// fixed order instead of autograd's two adds.  Each operand is contiguous inside a batch element and has its own batch stride
+// (the concatenation's gradient is consumed as the channel slice it is).
+template <bool VEC>
+__global__ void __launch_bounds__(256) add3_kernel(const float* __restrict__ a, long long a_bs, const float* __restrict__ b, long long b_bs,
+                                                   const float* __restrict__ c, long long c_bs, float* __restrict__ out, unsigned per,
+                                                   long long total) {
+    const DivU32 dv(per);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        unsigned q, r;
+        dv.divmod((unsigned)i, q, r);
+        if constexpr (VEC) {
+            const float4 x = *reinterpret_cast<const float4*>(a + q * a_bs + 4ll * r);
+            const float4 y = *reinterpret_cast<const float4*>(b + q * b_bs + 4ll * r);
+            const float4 z = *reinterpret_cast<const float4*>(c + q * c_bs + 4ll * r);
+            float4 o;
+            o.x = __fadd_rn(__fadd_rn(x.x, y.x), z.x); o.y = __fadd_rn(__fadd_rn(x.y, y.y), z.y);
+            o.z = __fadd_rn(__fadd_rn(x.z, y.z), z.z); o.w = __fadd_rn(__fadd_rn(x.w, y.w), z.w);
+            *reinterpret_cast<float4*>(out + 4ll * i) = o;
+        } else {
+            out[i] = __fadd_rn(__fadd_rn(a[q * a_bs + r], b[q * b_bs + r]), c[q * c_bs + r]);
+        }
+    }
+}
+
+LOCATE_API int locate_add3(const float* a, int64_t a_bs, const float* b, int64_t b_bs, const float* c, int64_t c_bs, float* out, int batch,
+                           int64_t per, void* stream) {
+    LOCATE_REQUIRE(a && b && c && out && batch > 0 && per > 0 && a_bs >= per && b_bs >= per && c_bs >= per &&
+                   (int64_t)batch * per < (1ll << 32), "locate_add3: bad arguments");
+    const bool vec = (per & 3) == 0 && ((a_bs | b_bs | c_bs) & 3) == 0 && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(out);
+    if (vec) {
+        const int64_t total = (int64_t)batch * (per / 4);
+        add3_kernel<true><<<stream_grid(total, 2048), 256, 0, as_stream(stream)>>>(a, a_bs, b, b_bs, c, c_bs, out, (unsigned)(per / 4), total);
+    } else {
+        const int64_t total = (int64_t)batch * per;
+        add3_kernel<false><<<stream_grid(total, 2048), 256, 0, as_stream(stream)>>>(a, a_bs, b, b_bs, c, c_bs, out, (unsigned)per, total);
+    }
+    LOCATE_LAUNCH_CHECK("locate_add3");
+    return LOCATE_OK;
+}
+
 LOCATE_API int locate_absmax_words(void) { return AMAX_WORDS; }
 
 // largest magnitude of x folded into the AMAX_WORDS words at slot (atomic max on the bit patterns; the caller zeroes them first)

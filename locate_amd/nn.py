@@ -207,16 +207,26 @@ class CatModule(_TwoBranch):
     input (every use in the two networks: libs/scale.py:28-34) it writes its result straight into its slice of the
     concatenation, and only the skip part is copied."""
 
-    def forward(self, function_input, layer_input=None, scale=None):
+    def in_place(self, x):
+        """whether forward(x) takes the write-in-place path (the conv's result lands in its slice of the concatenation)"""
         layer = self.layer_module
-        if (layer_input is None and scale is None and self.residual_module is _identity and isinstance(layer, SpectralNorm)
-                and isinstance(layer.module, nn.Conv2d) and function_input.dim() == 4 and function_input.is_cuda):
-            m = layer.module
+        if not (self.residual_module is _identity and isinstance(layer, SpectralNorm) and isinstance(layer.module, nn.Conv2d)
+                and x.dim() == 4 and x.is_cuda):
+            return False
+        m = layer.module
+        return (m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.groups == 1 and x.shape[1] == m.in_channels)
+
+    def forward(self, function_input, layer_input=None, scale=None, conv_alias=None):
+        """conv_alias: a second autograd alias of function_input for the conv (ops.fork3: the block sums the gradients of its
+        input's three consumers in one launch); only with the in-place path."""
+        if layer_input is None and scale is None and self.in_place(function_input):
             x = function_input
-            if (m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.groups == 1 and x.shape[1] == m.in_channels):
-                buf = x.new_empty((x.shape[0], x.shape[1] + m.out_channels) + tuple(x.shape[2:]))
-                branch = layer(x, out=buf[:, x.shape[1]:])
-                return ops.cat_channels(x, branch, [buf])
+            m = self.layer_module.module
+            buf = x.new_empty((x.shape[0], x.shape[1] + m.out_channels) + tuple(x.shape[2:]))
+            branch = self.layer_module(x if conv_alias is None else conv_alias, out=buf[:, x.shape[1]:])
+            return ops.cat_channels(x, branch, [buf])
+        if conv_alias is not None:
+            raise RuntimeError("CatModule: conv_alias needs the in-place path")
         return ops.cat_channels(*self._run(function_input, layer_input, scale))
 
 
@@ -463,11 +473,15 @@ class Block(nn.Module):
         # (Pooling FIRST on the down-sampling skip branch - the 2x2 mean commutes with the concatenation and the 1x1 conv - was
         # measured at -0.16 ms per step, but it changes the rounding order enough to move the ill-conditioned d(gamma) sums of
         # the 128x128 record from 5e-4 to 1e-3 of their reference values: the reference's order stays.)
+        conv_alias = None
         if isinstance(stages[0], (FeaturePooling, AvgPool2)):
             skip_in, conv_in = ops.fork(function_input)      # the pooling and the conv branch's norm share the gradient buffer
+        elif isinstance(stages[0], CatModule) and stages[0].in_place(function_input):
+            # three consumers (identity half of the concatenation, its 1x1 conv, the conv branch's norm): one summing launch
+            skip_in, conv_alias, conv_in = ops.fork3(function_input)
         skip = skip_in
-        for stage in stages:
-            skip = stage(skip)
+        for i, stage in enumerate(stages):
+            skip = stage(skip, conv_alias=conv_alias) if (i == 0 and conv_alias is not None) else stage(skip)
         out = self.res_module_i(skip, conv_in, scales[0])
         for gate, scale in zip(self._gates, scales[1:]):
             out = gate(out, scale=scale)

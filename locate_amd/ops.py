@@ -248,6 +248,7 @@ class Runtime:
         self._fin_sums = []
         self._fin_chan = []
         self._fin_norm = []
+        self._fin_wgrad = []             # packed SkwRec records (conv.hip): the pass's small-map weight gradients
         self._streams = {}               # streams on which this pass queued deferred work / produced late gradients
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
@@ -276,6 +277,7 @@ class Runtime:
         self._streams = {}
         AMAX.new_pass()
         self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan, self._fin_norm = [], [], [], [], []
+        self._fin_wgrad = []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
         self._dv_layers = {}
@@ -305,6 +307,12 @@ class Runtime:
         # batched dv below reads
         L = lib()
         st = _stream()
+        if self._fin_wgrad:              # first: the rank-1 launch below reads their <G, W_bar> partials and corrects their gw
+            cap = L.locate_wgrad_batch_max()
+            for i in range(0, len(self._fin_wgrad), cap):
+                chunk = self._fin_wgrad[i:i + cap]
+                check(L.locate_wgrad_batch(b"".join(chunk), len(chunk), st), "locate_wgrad_batch")
+            self._fin_wgrad = []
         for queue, fn, name in ((self._fin_dots, L.locate_fin_sn_dots, "locate_fin_sn_dots"),
                                 (self._fin_rank1, L.locate_fin_sn_rank1, "locate_fin_sn_rank1"),
                                 (self._fin_sums, L.locate_fin_sums, "locate_fin_sums"),
@@ -360,6 +368,11 @@ class Runtime:
         s1 = ws.data_ptr() + plane_offset
         self._fin_norm.append(self._rec([s1, s1 + 4 * planes, stats, dscale, dbias], [], [B, C, groups]))
         self._keep.append((ws, stats, dscale, dbias))
+        self._schedule_end()
+
+    def queue_small_wgrad(self, record, operands):
+        self._fin_wgrad.append(record)
+        self._keep.append(operands)
         self._schedule_end()
 
     def late_grad(self, param, grad):
@@ -555,6 +568,46 @@ def fork(x):
     if stats is not None:
         a._locate_stats = b._locate_stats = stats
     return a, b
+
+
+class Fork3Fn(torch.autograd.Function):
+    """x -> three aliases for a tensor with THREE consumers - a discriminator block's input feeds the conv branch's norm, the
+    identity half of the skip branch's concatenation and that branch's 1x1 conv (libs/block.py:38-52, libs/scale.py:28-34).
+    Autograd would sum the three gradients with two launches (one of them strided: the concatenation's gradient arrives as a
+    channel slice); here they are added in ONE pass over batch-strided operands, in a fixed order: (norm + slice) + conv."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_identity, g_conv, g_norm):
+        gs = [g for g in (g_norm, g_identity, g_conv) if g is not None]
+        if len(gs) == 3 and all(_batch_strided(g) for g in gs) and gs[0].shape == gs[1].shape == gs[2].shape:
+            a, b, c = gs
+            out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+            per = a[0].numel()
+            check(lib().locate_add3(_p(a), a.stride(0), _p(b), b.stride(0), _p(c), c.stride(0), _p(out), a.shape[0], per, _stream()),
+                  "locate_add3")
+            return out
+        total = None
+        for g in gs:
+            total = g if total is None else total + g
+        return total
+
+
+def _batch_strided(g):
+    """contiguous inside a batch element, any batch stride: what a channel slice of a contiguous tensor is"""
+    return (g.is_cuda and g.dtype == torch.float32 and g.dim() >= 2 and g.shape[0] > 0 and g[0].is_contiguous()
+            and (g.shape[0] == 1 or g.stride(0) >= g[0].numel()))
+
+
+def fork3(x):
+    """Three aliases of x for its three consumers, in the order (identity copy, conv, norm) - see Fork3Fn; x itself three
+    times when no gradient will flow."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x, x
+    return Fork3Fn.apply(x)
 
 
 def _slot_of(x):
@@ -1135,10 +1188,19 @@ def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0,
     return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like), precision, amax)
 
 
-def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0, amax_in=None, amax_out=None):
-    """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>."""
+def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0, amax_in=None, amax_out=None,
+                     rt=None):
+    """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>.
+    With a runtime that defers its finalisers, the layers on 1x1 maps / with one output pixel are only queued: one launch for
+    all of them at the end of the pass (Runtime.queue_small_wgrad)."""
     L = lib()
     st = _stream()
+    if spec.mode == "dense" and rt is not None and rt.defer_finalisers:
+        rec = ctypes.create_string_buffer(L.locate_wgrad_batch_record_bytes())
+        if L.locate_wgrad_batch_record(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst,
+                                       _p(partial), rec) > 0:
+            rt.queue_small_wgrad(rec.raw, (xin, gout, gw, w_ref, inv_sigma, partial))
+            return
     if spec.mode == "dense":
         ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), xin.device)
         f16 = _f16_ok(spec, geom, precision, amax_in, amax_out)
@@ -1184,7 +1246,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
-        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision, am_in, am_out)
+        _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision, am_in, am_out, rt)
         dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
         Bn, Mn = gy.shape[0], gy.shape[1]
         plane = gy.numel() // (Bn * Mn)
@@ -1204,7 +1266,7 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     # then the rank-1 spectral-norm correction in place
     npart = _weight_grad_partials(spec, geom, garr)
     partial = torch.empty(npart, dtype=torch.float64, device=x.device)
-    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision, am_in, am_out)
+    _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, 0, 0, partial, rt.precision, am_in, am_out, rt)
     dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
     if rt.defer_finalisers:
         rt.queue_sn_rank1(partial, npart, 0, sigma, 0, u, v, wv, 0, gw, gu, dsig, h, wd)

@@ -367,7 +367,11 @@ def test_conv_fp16_pieces_vs_cpu(kind, cin, cout, k, s, p, B, H, W, monkeypatch)
     before = dict(ops.F16_CALLS)
     yg = mod(xg)
     yg.backward(ops.tag_amax(g.to(dev())))
-    assert all(ops.F16_CALLS[kk] == before[kk] + 1 for kk in ("fwd", "dgrad", "wgrad")), (before, ops.F16_CALLS)
+    # the weight gradient of a layer with one output pixel is a plain fp32 outer-product kernel at every precision setting, queued
+    # for the pass's batched launch (locate_wgrad_batch): it never reaches the piece-form selection
+    one_pixel = (tuple(yr.shape[2:]) if kind == "conv" else (H, W)) == (1, 1)      # output side of the regular conv R
+    assert all(ops.F16_CALLS[kk] == before[kk] + 1 for kk in ("fwd", "dgrad")), (before, ops.F16_CALLS)
+    assert ops.F16_CALLS["wgrad"] == before["wgrad"] + (0 if one_pixel else 1), (before, ops.F16_CALLS)
     assert_close(yg.cpu(), yr, 2e-5, "y")
     assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
     assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
@@ -925,3 +929,102 @@ def test_style_link_fused_equals_separate_launches():
     for (k, a), (_, b) in zip(lm.named_parameters(), lm2.named_parameters()):
         if a.grad is not None or b.grad is not None:
             assert_close(a.grad.cpu(), b.grad.cpu(), 1e-5, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,extra", [((6, 8, 4, 4), 4), ((3, 5, 1, 1), 2), ((2, 3, 3, 5), 7), ((192, 32, 32, 32), 32)])
+def test_add3_strided_operands(shape, extra):
+    """locate_add3 (ops.Fork3Fn): (a + b) + c with a a channel slice of a wider tensor, against the same two adds in torch -
+    bit for bit (both round each add once, in the same order)."""
+    from locate_amd._lib import check, lib
+    torch.manual_seed(5)
+    B, C = shape[0], shape[1]
+    wide = torch.randn((B, C + extra) + shape[2:], device=dev())
+    a = wide[:, :C]
+    b, c = torch.randn(shape, device=dev()), torch.randn(shape, device=dev())
+    out = torch.empty(shape, device=dev())
+    per = b[0].numel()
+    check(lib().locate_add3(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), out.data_ptr(), B, per,
+                            torch.cuda.current_stream().cuda_stream), "locate_add3")
+    assert torch.equal(out, (a + b) + c)
+
+
+@pytest.mark.gpu
+def test_fork3_sums_three_gradients_in_one_launch():
+    """A discriminator block's input has three consumers (norm of the conv branch, identity half of the concatenation, the skip
+    branch's 1x1 conv): with ops.fork3 the three gradients are summed by one kernel; the result equals autograd's own sum of the
+    same three gradients up to the order of two roundings."""
+    from locate_amd import ops
+    from locate_amd.nn import Block
+    torch.manual_seed(11)
+    blk = Block(16, 8, 16, 2, False, 1).to(dev())          # down-sampling stage, more channels out than in: CatModule + AvgPool2
+    import copy
+    blk2 = copy.deepcopy(blk)              # every forward advances the power iteration: the second run needs its own u, v
+    x1 = torch.randn(4, 8, 16, 16, device=dev(), requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = blk(x1)
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    real = ops.fork3
+    ops.fork3 = lambda t: (t, t, t)          # the same block with autograd's own accumulation
+    try:
+        y2 = blk2(x2)
+        y2.backward(g)
+    finally:
+        ops.fork3 = real
+    assert torch.equal(y1, y2)
+    assert_close(x1.grad.cpu(), x2.grad.cpu(), 2e-6, "block input gradient")
+    n = 0
+    for (k, p), (_, q) in zip(blk.named_parameters(), blk2.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is not None:
+            n += 1
+            assert_close(p.grad.cpu(), q.grad.cpu(), 1e-6, k)
+    assert n > 4
+
+
+@pytest.mark.gpu
+def test_small_weight_gradients_batched_equal_single_launches():
+    """locate_wgrad_batch: the pass's 1x1-map / one-output-pixel weight gradients in one launch are bit for bit the single
+    launches' (same kernel body per layer), including the <G, W_bar> partials and the zeroed taps of the one-pixel layers."""
+    import ctypes
+    from locate_amd import ops
+    from locate_amd._lib import check, lib
+    L = lib()
+    torch.manual_seed(2)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [("conv", 1, 1, 1, 0, 24, 40, 1, 64), ("conv", 1, 1, 1, 0, 832, 384, 1, 64), ("conv", 5, 5, 2, 2, 16, 16, 2, 12),
+             ("conv", 3, 3, 1, 1, 32, 8, 1, 6), ("conv", 1, 1, 1, 0, 7, 3, 1, 5)]
+    recs, expect, outs, keep = [], [], [], []
+    for kind, kh, kw, s, p, cin, cout, H, B in cases:
+        spec = ops.ConvSpec(kind, kh, kw, s, p, p)
+        x = torch.randn(B, cin, H, H, device=dev())
+        w = torch.randn(cout, cin, kh, kw, device=dev())
+        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+        garr = (ctypes.c_int * 12)(*geom)
+        gy = torch.randn(out_shape, device=dev())
+        inv = torch.full((1,), 0.37, device=dev())
+        npart = L.locate_conv_wgrad_partials(garr)
+        gw1, gw2 = torch.full_like(w, 7.0), torch.full_like(w, -3.0)
+        p1, p2 = torch.zeros(npart, dtype=torch.float64, device=dev()), torch.zeros(npart, dtype=torch.float64, device=dev())
+        check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw1.data_ptr(), w.data_ptr(), inv.data_ptr(),
+                                  0, 0, p1.data_ptr(), None, 0, None, None, st), "locate_conv_wgrad")
+        rec = ctypes.create_string_buffer(L.locate_wgrad_batch_record_bytes())
+        blocks = L.locate_wgrad_batch_record(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw2.data_ptr(), w.data_ptr(),
+                                             inv.data_ptr(), 0, 0, p2.data_ptr(), rec)
+        assert blocks > 0, (kind, kh, cin, cout, H)
+        recs.append(rec.raw)
+        expect.append((gw1, p1))
+        outs.append((gw2, p2))
+        keep.append((x, w, gy, inv))
+    check(L.locate_wgrad_batch(b"".join(recs), len(recs), st), "locate_wgrad_batch")
+    torch.cuda.synchronize()
+    for (g1, q1), (g2, q2) in zip(expect, outs):
+        assert torch.equal(g1, g2) and torch.equal(q1, q2)
+    # a layer the batch does not take: the caller launches it on its own
+    spec = ops.ConvSpec("conv", 3, 3, 1, 1, 1, 1)
+    geom, _ = spec.geometry((2, 4, 8, 8), (4, 4, 3, 3))
+    rec = ctypes.create_string_buffer(L.locate_wgrad_batch_record_bytes())
+    t = torch.zeros(4096, device=dev())
+    assert L.locate_wgrad_batch_record((ctypes.c_int * 12)(*geom), t.data_ptr(), 256, t.data_ptr(), 256, t.data_ptr(), None, None, 0, 0,
+                                       None, rec) == 0
