@@ -203,10 +203,18 @@ int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const flo
  * (gw = sum_k G_k / sigma_k over stacked forward calls; <= 4 groups; w_ref and inner_partial must be null). */
 size_t locate_conv_wgrad_workspace_bytes(const int* geom);
 int locate_conv_wgrad_partials(const int* geom);
+/* deferred_reduce (nullable; host memory, locate_slab_reduce_record_bytes() bytes): the split reduction of this launch is not
+ * run but written there; gw / inner_partial are complete after locate_slab_reduce_batch() has run the record (at most
+ * locate_slab_reduce_max() records per call; the workspace stays untouched until then).  locate_slab_reduce_record_blocks() == 0:
+ * the geometry has no split reduction, nothing is pending.  One launch then finishes ALL weight gradients of a backward pass. */
 int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
                       double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
-                      void* stream);
+                      void* deferred_reduce, void* stream);
+size_t locate_slab_reduce_record_bytes(void);
+int locate_slab_reduce_max(void);
+int locate_slab_reduce_record_blocks(const void* record);
+int locate_slab_reduce_batch(const void* records, int n, void* stream);
 
 /* The weight gradients of ALL small-map layers of one backward pass in ONE launch: the style chain's linears
  * (libs/linear.py:7-15, libs/block.py:112-127), the channel gates' squeeze convs, the discriminator's layers on 1x1 maps, its

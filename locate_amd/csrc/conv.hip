@@ -2243,17 +2243,17 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 // ZP = 1: one thread per element walks all slabs.  ZP = 4: four z-groups per element (many slabs, few elements: the
 // 1x1 / attention layers), combined through LDS in a fixed order - results stay bit-reproducible.
 template <int ZP>
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
-                                                          int nsplit, const float* __restrict__ w_ref,
-                                                          const float* __restrict__ inv_scale, double* __restrict__ partial) {
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
+                                                 const float* __restrict__ w_ref, const float* __restrict__ inv_scale,
+                                                 double* __restrict__ partial, int bid, int nblocks) {
     __shared__ double scratch[16];
     __shared__ float zsum[ZP][256 / ZP];
     const float sc = inv_scale ? inv_scale[0] : 1.0f;
     constexpr int EPB = 256 / ZP;                       // elements per block pass
     const int ex = threadIdx.x % EPB, ez = threadIdx.x / EPB;
-    const int64_t stride = (int64_t)gridDim.x * EPB;
+    const int64_t stride = (int64_t)nblocks * EPB;
     double dot = 0.0;
-    for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < n; i0 += stride) {
+    for (int64_t i0 = (int64_t)bid * EPB; i0 < n; i0 += stride) {
         const int64_t i = i0 + ex;
         float acc = 0.0f;
         if (i < n) {
@@ -2283,8 +2283,40 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
     }
     if (partial) {
         dot = block_sum<double>(dot, scratch);
-        if (threadIdx.x == 0) partial[blockIdx.x] = dot;
+        if (threadIdx.x == 0) partial[bid] = dot;
     }
+}
+
+template <int ZP>
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
+                                                          int nsplit, const float* __restrict__ w_ref,
+                                                          const float* __restrict__ inv_scale, double* __restrict__ partial) {
+    slab_reduce_body<ZP>(slab, out, n, nsplit, w_ref, inv_scale, partial, blockIdx.x, gridDim.x);
+}
+
+// The split reductions of ALL weight gradients of one backward pass in one launch: a weight gradient only feeds a parameter
+// gradient, so its slab sum can wait for the end of the pass like the other finalisers (finalise.hip) - each of the ~30 per
+// iteration is a launch-floor-sized kernel behind its GEMM.  Records by value; per layer the same blocks, the same z order and
+// the same <G, W_bar> partials as the single launch.
+struct SlabRec {
+    const float* slab; float* out; const float* w_ref; const float* inv_scale; double* partial;
+    long long n;
+    int nsplit, zp, grid, block0;
+};
+#define SLAB_MAX 32
+struct SlabBatch {
+    SlabRec r[SLAB_MAX];
+};
+
+__global__ void __launch_bounds__(256) slab_reduce_batch_kernel(const SlabBatch b, int nrec) {
+    int k = 0;
+    for (int i = 1; i < nrec; ++i)
+        if ((int)blockIdx.x >= b.r[i].block0) k = i;          // block0 ascending
+    const SlabRec& r = b.r[k];
+    const int bid = (int)blockIdx.x - r.block0;
+    if (r.zp == 16) slab_reduce_body<16>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
+    else if (r.zp == 4) slab_reduce_body<4>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
+    else slab_reduce_body<1>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
 }
 
 static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int* tiles_out) {
@@ -2766,10 +2798,14 @@ LOCATE_API int locate_wgrad_batch(const void* records, int n, void* stream) {
 // spectral-norm backward needs come out of the same pass (locate_conv_wgrad_partials(geom) doubles).
 // scale_group_batch > 0: gy of batch element b is weighted by inv_scale[(b / scale_group_batch) * scale_stride] instead
 // (stacked forwards; at most 4 groups; w_ref / inner_partial must then be null - see locate_sn_group_dsigma).
+// deferred_reduce (nullable, host memory of locate_slab_reduce_record_bytes() bytes): the split reduction - when this geometry has
+// one - is NOT launched; its launch is written there instead and gw / inner_partial are complete only after
+// locate_slab_reduce_batch() has run that record (the workspace must stay untouched until then).  The record's block count is
+// locate_slab_reduce_record_blocks(record): 0 = nothing pending (gw is complete when this launch is).
 LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, float* gw,
                                  const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
                                  double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
-                                 void* stream) {
+                                 void* deferred_reduce, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
     LOCATE_REQUIRE(precision >= 0 && precision <= 2, "locate_conv_wgrad: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)");
@@ -2779,6 +2815,23 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
                    g.B / scale_group_batch <= 4 && !w_ref && !inner_partial)), "locate_conv_wgrad: bad group scaling arguments");
     hipStream_t st = as_stream(stream);
+    if (deferred_reduce) memset(deferred_reduce, 0, sizeof(SlabRec));
+    auto reduce = [&](const float* slab, int64_t n, int nsplit, const float* scale, const char* who) -> int {
+        const int rg = wgrad_reduce_grid(n, nsplit);
+        const int zp = wgrad_reduce_zp(nsplit, n);
+        if (deferred_reduce) {
+            SlabRec r;
+            r.slab = slab; r.out = gw; r.w_ref = w_ref; r.inv_scale = scale; r.partial = inner_partial;
+            r.n = n; r.nsplit = nsplit; r.zp = zp; r.grid = rg; r.block0 = 0;
+            memcpy(deferred_reduce, &r, sizeof(r));
+            return LOCATE_OK;
+        }
+        if (zp == 16) slab_reduce_kernel<16><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
+        else if (zp == 4) slab_reduce_kernel<4><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
+        else slab_reduce_kernel<1><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
+        LOCATE_LAUNCH_CHECK(who);
+        return LOCATE_OK;
+    };
     if (skinny_wgrad_ok(g)) {          // 1x1 maps: plain fp32 FMAs at either precision setting (see skinny_rows_kernel)
         skinny_wgrad_kernel<<<skinny_wgrad_grid(g), 256, 0, st>>>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_group_batch, scale_stride,
                                                                   inner_partial, g.B, g.M, g.C, OnePix{0, 0, 0, 0, 0, 0, 0});
@@ -2820,14 +2873,7 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
             else pw_wgrad_kernel<2, 2, 3><<<grid, 256, 0, st>>>(q);
         }
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(pointwise)");
-        const int64_t n = (int64_t)g.M * g.C;
-        const int rg = wgrad_reduce_grid(n, pq.nslab);
-        const int zp = wgrad_reduce_zp(pq.nslab, n);
-        if (zp == 16) slab_reduce_kernel<16><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        else if (zp == 4) slab_reduce_kernel<4><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        else slab_reduce_kernel<1><<<rg, 256, 0, st>>>(q.slab, gw, n, pq.nslab, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(pointwise reduce)");
-        return LOCATE_OK;
+        return reduce(q.slab, (int64_t)g.M * g.C, pq.nslab, grouped ? nullptr : inv_scale, "locate_conv_wgrad(pointwise reduce)");
     }
     int bm, nsplit, chunk, tiles;
     wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
@@ -2874,16 +2920,32 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
     else conv_wgrad_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     LOCATE_LAUNCH_CHECK("locate_conv_wgrad(gemm)");
-    if (!direct) {
-        const int64_t n = (int64_t)g.M * p.R;
-        const int rg = wgrad_reduce_grid(n, nsplit);
-        if (wgrad_reduce_zp(nsplit, n) == 16)
-            slab_reduce_kernel<16><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        else if (wgrad_reduce_zp(nsplit, n) == 4)
-            slab_reduce_kernel<4><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        else
-            slab_reduce_kernel<1><<<rg, 256, 0, st>>>(p.slab, gw, n, nsplit, w_ref, grouped ? nullptr : inv_scale, inner_partial);
-        LOCATE_LAUNCH_CHECK("locate_conv_wgrad(reduce)");
+    if (!direct) return reduce(p.slab, (int64_t)g.M * p.R, nsplit, grouped ? nullptr : inv_scale, "locate_conv_wgrad(reduce)");
+    return LOCATE_OK;
+}
+
+LOCATE_API size_t locate_slab_reduce_record_bytes(void) { return sizeof(SlabRec); }
+LOCATE_API int locate_slab_reduce_max(void) { return SLAB_MAX; }
+LOCATE_API int locate_slab_reduce_record_blocks(const void* record) {
+    if (!record) return 0;
+    SlabRec r;
+    memcpy(&r, record, sizeof(r));
+    return r.grid;
+}
+// Runs n deferred split reductions (records written by locate_conv_wgrad(deferred_reduce), packed, host memory) in one grid.
+LOCATE_API int locate_slab_reduce_batch(const void* records, int n, void* stream) {
+    LOCATE_REQUIRE(records && n > 0 && n <= SLAB_MAX, "locate_slab_reduce_batch: 1 .. locate_slab_reduce_max() records");
+    SlabBatch b;
+    memcpy(b.r, records, (size_t)n * sizeof(SlabRec));
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const SlabRec& r = b.r[i];
+        LOCATE_REQUIRE(r.slab && r.out && r.n > 0 && r.nsplit > 0 && r.grid > 0 && (r.zp == 1 || r.zp == 4 || r.zp == 16),
+                       "locate_slab_reduce_batch: bad record");
+        b.r[i].block0 = (int)blocks;
+        blocks += r.grid;
     }
+    slab_reduce_batch_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(b, n);
+    LOCATE_LAUNCH_CHECK("locate_slab_reduce_batch");
     return LOCATE_OK;
 }

@@ -249,6 +249,7 @@ class Runtime:
         self._fin_chan = []
         self._fin_norm = []
         self._fin_wgrad = []             # packed SkwRec records (conv.hip): the pass's small-map weight gradients
+        self._fin_slab = []              # packed SlabRec records (conv.hip): the split reductions of its other weight gradients
         self._streams = {}               # streams on which this pass queued deferred work / produced late gradients
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
@@ -277,7 +278,7 @@ class Runtime:
         self._streams = {}
         AMAX.new_pass()
         self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan, self._fin_norm = [], [], [], [], []
-        self._fin_wgrad = []
+        self._fin_wgrad, self._fin_slab = [], []
         for entry in self._dv_layers.values():
             entry[5]["k"] = 0
         self._dv_layers = {}
@@ -313,6 +314,12 @@ class Runtime:
                 chunk = self._fin_wgrad[i:i + cap]
                 check(L.locate_wgrad_batch(b"".join(chunk), len(chunk), st), "locate_wgrad_batch")
             self._fin_wgrad = []
+        if self._fin_slab:
+            cap = L.locate_slab_reduce_max()
+            for i in range(0, len(self._fin_slab), cap):
+                chunk = self._fin_slab[i:i + cap]
+                check(L.locate_slab_reduce_batch(b"".join(chunk), len(chunk), st), "locate_slab_reduce_batch")
+            self._fin_slab = []
         for queue, fn, name in ((self._fin_dots, L.locate_fin_sn_dots, "locate_fin_sn_dots"),
                                 (self._fin_rank1, L.locate_fin_sn_rank1, "locate_fin_sn_rank1"),
                                 (self._fin_sums, L.locate_fin_sums, "locate_fin_sums"),
@@ -372,6 +379,11 @@ class Runtime:
 
     def queue_small_wgrad(self, record, operands):
         self._fin_wgrad.append(record)
+        self._keep.append(operands)
+        self._schedule_end()
+
+    def queue_slab_reduce(self, record, operands):
+        self._fin_slab.append(record)
         self._keep.append(operands)
         self._schedule_end()
 
@@ -1202,12 +1214,19 @@ def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst
             rt.queue_small_wgrad(rec.raw, (xin, gout, gw, w_ref, inv_sigma, partial))
             return
     if spec.mode == "dense":
-        ws = _ws(L.locate_conv_wgrad_workspace_bytes(garr), xin.device)
+        nbytes = L.locate_conv_wgrad_workspace_bytes(garr)
+        defer = rt is not None and rt.defer_finalisers and nbytes > 0
+        # a deferred split reduction reads its slab at the end of the pass: the layer gets a slab of its own instead of the
+        # shared scratch buffer
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xin.device) if defer else _ws(nbytes, xin.device)
+        rec = ctypes.create_string_buffer(L.locate_slab_reduce_record_bytes()) if defer else None
         f16 = _f16_ok(spec, geom, precision, amax_in, amax_out)
         F16_CALLS["wgrad"] += int(f16)
         check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial),
-                                  _p(ws), 2 if f16 else precision, _p(amax_in) if f16 else None, _p(amax_out) if f16 else None, st),
+                                  _p(ws), 2 if f16 else precision, _p(amax_in) if f16 else None, _p(amax_out) if f16 else None, rec, st),
               "locate_conv_wgrad")
+        if defer and L.locate_slab_reduce_record_blocks(rec) > 0:
+            rt.queue_slab_reduce(rec.raw, (ws, gw, w_ref, inv_sigma, partial))
     elif spec.mode == "depthwise":
         ws = _ws(L.locate_dwconv_wgrad_workspace_bytes(garr), xin.device)
         check(L.locate_dwconv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst,

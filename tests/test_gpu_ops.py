@@ -1008,7 +1008,7 @@ def test_small_weight_gradients_batched_equal_single_launches():
         gw1, gw2 = torch.full_like(w, 7.0), torch.full_like(w, -3.0)
         p1, p2 = torch.zeros(npart, dtype=torch.float64, device=dev()), torch.zeros(npart, dtype=torch.float64, device=dev())
         check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw1.data_ptr(), w.data_ptr(), inv.data_ptr(),
-                                  0, 0, p1.data_ptr(), None, 0, None, None, st), "locate_conv_wgrad")
+                                  0, 0, p1.data_ptr(), None, 0, None, None, None, st), "locate_conv_wgrad")
         rec = ctypes.create_string_buffer(L.locate_wgrad_batch_record_bytes())
         blocks = L.locate_wgrad_batch_record(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw2.data_ptr(), w.data_ptr(),
                                              inv.data_ptr(), 0, 0, p2.data_ptr(), rec)
@@ -1028,3 +1028,46 @@ def test_small_weight_gradients_batched_equal_single_launches():
     t = torch.zeros(4096, device=dev())
     assert L.locate_wgrad_batch_record((ctypes.c_int * 12)(*geom), t.data_ptr(), 256, t.data_ptr(), 256, t.data_ptr(), None, None, 0, 0,
                                        None, rec) == 0
+
+
+@pytest.mark.gpu
+def test_deferred_split_reductions_equal_immediate_ones():
+    """locate_conv_wgrad(deferred_reduce) + locate_slab_reduce_batch: the split reductions of several weight gradients in one
+    launch at the end are bit for bit the reductions each launch would have run itself (gw and the <G, W_bar> partials)."""
+    import ctypes
+    from locate_amd import ops
+    from locate_amd._lib import check, lib
+    L = lib()
+    torch.manual_seed(4)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [("conv", 5, 2, 2, 32, 32, 16, 24), ("conv", 1, 1, 0, 48, 48, 32, 16), ("conv", 3, 1, 1, 48, 48, 32, 8),
+             ("conv", 1, 1, 0, 256, 512, 2, 48), ("conv", 4, 2, 1, 96, 96, 16, 8), ("conv", 3, 1, 1, 8, 8, 4, 2)]
+    recs, pending, keep = [], [], []
+    for kind, k, s, p, cin, cout, H, B in cases:
+        spec = ops.ConvSpec(kind, k, k, s, p, p)
+        x = torch.randn(B, cin, H, H, device=dev())
+        w = torch.randn(cout, cin, k, k, device=dev())
+        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+        garr = (ctypes.c_int * 12)(*geom)
+        gy = torch.randn(out_shape, device=dev())
+        inv = torch.full((1,), 1.7, device=dev())
+        npart = L.locate_conv_wgrad_partials(garr)
+        nws = max(L.locate_conv_wgrad_workspace_bytes(garr), 16)
+        res = []
+        for deferred in (False, True):
+            gw = torch.full_like(w, 5.0)
+            part = torch.zeros(npart, dtype=torch.float64, device=dev())
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+            rec = ctypes.create_string_buffer(L.locate_slab_reduce_record_bytes()) if deferred else None
+            check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(), w.data_ptr(),
+                                      inv.data_ptr(), 0, 0, part.data_ptr(), ws.data_ptr(), 0, None, None, rec, st), "locate_conv_wgrad")
+            if deferred and L.locate_slab_reduce_record_blocks(rec) > 0:
+                recs.append(rec.raw)
+            res.append((gw, part))
+            keep.append((ws, x, gy, inv, w))          # the deferred reduction reads the slab and w at the END
+        pending.append(res)
+    assert len(recs) >= 4              # the last case is a single-block launch without a split: nothing pending for it
+    check(L.locate_slab_reduce_batch(b"".join(recs), len(recs), st), "locate_slab_reduce_batch")
+    torch.cuda.synchronize()
+    for (g1, p1), (g2, p2) in pending:
+        assert torch.equal(g1, g2) and torch.equal(p1, p2)

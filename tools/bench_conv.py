@@ -109,13 +109,13 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
         fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
         wgr = lambda: check(L.locate_conv_wgrad(garr, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
                                                 w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec,
-                                                slot[x.data_ptr()] if prec == 2 else None, slot[gy.data_ptr()] if prec == 2 else None, S()))
+                                                slot[x.data_ptr()] if prec == 2 else None, slot[gy.data_ptr()] if prec == 2 else None, None, S()))
         flops = 2.0 * B * out_shape[2] * out_shape[3] * cout * cin * kh * kw
     else:
         fwd, dgr = (lambda: r_dgrad(x, y)), (lambda: r_fwd(gy, gx))
         wgr = lambda: check(L.locate_conv_wgrad(garr, gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(),
                                                 w.data_ptr(), one.data_ptr(), 0, 0, part.data_ptr(), ws_w.data_ptr(), prec,
-                                                slot[gy.data_ptr()] if prec == 2 else None, slot[x.data_ptr()] if prec == 2 else None, S()))
+                                                slot[gy.data_ptr()] if prec == 2 else None, slot[x.data_ptr()] if prec == 2 else None, None, S()))
         flops = 2.0 * B * H * W * cout * cin * kh * kw        # every input pixel meets every tap once
     if CHECK:
         import torch.nn.functional as F
