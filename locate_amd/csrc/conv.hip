@@ -2581,24 +2581,28 @@ struct OnePix {
     int hw, W, KH, KW, pad_h, pad_w, Cw;
 };
 
-#define SKW_MT 8          // gradient rows per block
+#define SKW_MT 8          // gradient rows per block (narrow layers)
+#define SKW_MT_WIDE 32    // ... of layers with >= SKW_WIDE_M rows: x is re-read by a quarter as many blocks
+#define SKW_WIDE_M 128
+static inline int skw_mt(int M) { return M >= SKW_WIDE_M ? SKW_MT_WIDE : SKW_MT; }
 #define SKW_NC 32         // batch rows per load batch
 
+template <int MT>
 __device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
                                                   long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
                                                   const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
                                                   double* __restrict__ partial, int N, int M, int C, const OnePix& op, int bx, int by,
                                                   int grid_x) {
     __shared__ double scratch[16];
-    __shared__ float red[4][SKW_MT][64];
+    __shared__ float red[4][MT][64];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int j = bx * 64 + lane;
-    const int i0 = by * SKW_MT;
+    const int i0 = by * MT;
     const bool jok = j < C;
     const float* __restrict__ xc = x + (jok ? j : 0);
-    float acc[SKW_MT];
+    float acc[MT];
 #pragma unroll
-    for (int t = 0; t < SKW_MT; ++t) acc[t] = 0.0f;
+    for (int t = 0; t < MT; ++t) acc[t] = 0.0f;
     // the four waves take a quarter of the batch rows each; their partial sums are added in wave order below
     const int nq = (N + 3) / 4, nlo = wid * nq, nhi = nlo + nq < N ? nlo + nq : N;
     for (int nb = nlo; nb < nhi; nb += SKW_NC) {
@@ -2609,25 +2613,26 @@ __device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, l
         for (int q = 0; q < SKW_NC; ++q) {
             if (nb + q < nhi) {
                 const float* __restrict__ g = gy + (long long)(nb + q) * gy_bs + i0;          // wave-uniform: scalar loads
-                const float s = scale_bg ? inv_scale[((nb + q) / scale_bg) * scale_stride] : 1.0f;
-                if (i0 + SKW_MT <= M) {
+                // a stacked call's 1 / sigma_k goes onto the x value (one multiply per batch row instead of one per row and m)
+                const float xs = scale_bg ? xv[q] * inv_scale[((nb + q) / scale_bg) * scale_stride] : xv[q];
+                if (i0 + MT <= M) {
 #pragma unroll
-                    for (int t = 0; t < SKW_MT; ++t) acc[t] = fmaf(g[t] * s, xv[q], acc[t]);
+                    for (int t = 0; t < MT; ++t) acc[t] = fmaf(g[t], xs, acc[t]);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < SKW_MT; ++t) acc[t] = fmaf((i0 + t < M ? g[t] : 0.0f) * s, xv[q], acc[t]);
+                    for (int t = 0; t < MT; ++t) acc[t] = fmaf(i0 + t < M ? g[t] : 0.0f, xs, acc[t]);
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < SKW_MT; ++t) red[wid][t][lane] = acc[t];
+    for (int t = 0; t < MT; ++t) red[wid][t][lane] = acc[t];
     __syncthreads();
     const float sc = (!scale_bg && inv_scale) ? inv_scale[0] : 1.0f;
     double dot = 0.0;
 #pragma unroll
-    for (int q = 0; q < SKW_MT / 4; ++q) {          // wave w finishes rows 2w, 2w + 1
-        const int t = wid * (SKW_MT / 4) + q;
+    for (int q = 0; q < MT / 4; ++q) {          // wave w finishes rows (MT / 4) w ... (MT / 4) (w + 1) - 1
+        const int t = wid * (MT / 4) + q;
         if (jok && i0 + t < M) {
             const float v = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
             long long o = (long long)(i0 + t) * C + j;
@@ -2656,7 +2661,7 @@ __device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, l
         int c_last = (first_col + 63) / op.hw;
         if (c_last > op.Cw - 1) c_last = op.Cw - 1;
         const int span = (c_last - c_first + 1) * taps;
-        for (int t = 0; t < SKW_MT; ++t) {
+        for (int t = 0; t < MT; ++t) {
             if (i0 + t >= M) break;
             float* row = gw + ((long long)(i0 + t) * op.Cw + c_first) * taps;
             for (int e = threadIdx.x; e < span; e += blockDim.x) {
@@ -2675,8 +2680,12 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
                                                            long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
                                                            const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
                                                            double* __restrict__ partial, int N, int M, int C, OnePix op) {
-    skinny_wgrad_body(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x, blockIdx.y,
-                      gridDim.x);
+    if (M >= SKW_WIDE_M)
+        skinny_wgrad_body<SKW_MT_WIDE>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x,
+                                       blockIdx.y, gridDim.x);
+    else
+        skinny_wgrad_body<SKW_MT>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x,
+                                  blockIdx.y, gridDim.x);
 }
 
 // The same for ALL such layers of one backward pass in ONE launch (the style chain's links, the channel gates' squeeze convs,
@@ -2702,20 +2711,24 @@ __global__ void __launch_bounds__(256) skinny_wgrad_batch_kernel(const SkwBatch 
     const SkwRec& r = b.r[k];
     const int local = (int)blockIdx.x - r.block0;
     const int by = local / r.grid_x, bx = local - by * r.grid_x;
-    skinny_wgrad_body(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N, r.M, r.C, r.op,
-                      bx, by, r.grid_x);
+    if (r.M >= SKW_WIDE_M)
+        skinny_wgrad_body<SKW_MT_WIDE>(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N,
+                                       r.M, r.C, r.op, bx, by, r.grid_x);
+    else
+        skinny_wgrad_body<SKW_MT>(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N, r.M,
+                                  r.C, r.op, bx, by, r.grid_x);
 }
 
 static bool skinny_wgrad_ok(const ConvGeom& g) {
     return !path_disabled("skinny") && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad_h == 0 && g.pad_w == 0 && g.H == 1 &&
            g.W == 1 && g.OH == 1 && g.OW == 1;
 }
-static dim3 skinny_wgrad_grid(const ConvGeom& g) { return dim3((g.C + 63) / 64, (g.M + SKW_MT - 1) / SKW_MT); }
+static dim3 skinny_wgrad_grid(const ConvGeom& g) { return dim3((g.C + 63) / 64, (g.M + skw_mt(g.M) - 1) / skw_mt(g.M)); }
 // one output pixel, a kernel larger than 1x1 (see OnePix); the input map is small by construction (it fits under the kernel)
 static bool onepix_wgrad_ok(const ConvGeom& g) {
     return !path_disabled("skinny") && !skinny_wgrad_ok(g) && g.OH == 1 && g.OW == 1 && (long long)g.C * g.H * g.W < (1 << 24);
 }
-static dim3 onepix_wgrad_grid(const ConvGeom& g) { return dim3((g.C * g.H * g.W + 63) / 64, (g.M + SKW_MT - 1) / SKW_MT); }
+static dim3 onepix_wgrad_grid(const ConvGeom& g) { return dim3((g.C * g.H * g.W + 63) / 64, (g.M + skw_mt(g.M) - 1) / skw_mt(g.M)); }
 
 LOCATE_API size_t locate_conv_wgrad_workspace_bytes(const int* geom) {
     const ConvGeom g = make_geom(geom);
@@ -2785,7 +2798,7 @@ LOCATE_API int locate_wgrad_batch(const void* records, int n, void* stream) {
         const SkwRec& r = b.r[i];
         LOCATE_REQUIRE(r.x && r.gy && r.gw && r.grid_x > 0 && r.M > 0 && r.C > 0 && r.N > 0, "locate_wgrad_batch: bad record");
         b.r[i].block0 = (int)blocks;
-        blocks += (long long)r.grid_x * ((r.M + SKW_MT - 1) / SKW_MT);
+        blocks += (long long)r.grid_x * ((r.M + skw_mt(r.M) - 1) / skw_mt(r.M));
     }
     LOCATE_REQUIRE(blocks < (1ll << 31), "locate_wgrad_batch: too many blocks");
     skinny_wgrad_batch_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(b, n);
