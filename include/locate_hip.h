@@ -211,6 +211,13 @@ int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, const float
                       const float* w_ref, const float* inv_scale, int scale_group_batch, int scale_stride,
                       double* inner_partial, void* workspace, int precision, const void* x_absmax, const void* gy_absmax,
                       void* deferred_reduce, void* stream);
+/* Stacked calls (scale_group_batch > 0) WITH w_ref + inner_partial: the split reduction is laid out so that no slab crosses a
+ * call boundary and emits the partial sums of <G_k / sigma_k, W_bar> per call - inner_partial[call][partial], groups x
+ * locate_conv_wgrad_group_partials(geom, groups) doubles, workspace of locate_conv_wgrad_group_workspace_bytes(geom, groups) bytes.
+ * Their sum over the partials equals <gy_k, y_k - bias> (locate_fin_sn_dots), without reading gy and y again.  0 partials: this
+ * geometry cannot (1x1 maps, one output pixel, call lengths that do not divide into whole slabs) - use locate_fin_sn_dots. */
+int locate_conv_wgrad_group_partials(const int* geom, int groups);
+size_t locate_conv_wgrad_group_workspace_bytes(const int* geom, int groups);
 size_t locate_slab_reduce_record_bytes(void);
 int locate_slab_reduce_max(void);
 int locate_slab_reduce_record_blocks(const void* record);

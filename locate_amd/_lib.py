@@ -86,6 +86,8 @@ PROTOTYPES = {
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
     "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "locate_conv_wgrad_group_partials": (c_i, [c_ip, c_i]),
+    "locate_conv_wgrad_group_workspace_bytes": (c_sz, [c_ip, c_i]),
     "locate_slab_reduce_record_bytes": (c_sz, []),
     "locate_slab_reduce_max": (c_i, []),
     "locate_slab_reduce_record_blocks": (c_i, [c_p]),

@@ -1805,6 +1805,8 @@ struct WgParams {
     int R;              // C * KH * KW
     int N;              // B * OH * OW
     int chunk;          // reduction elements per split (multiple of WG_BK)
+    int zper, Ng;       // splits per stacked call and reduction elements per call: split z covers elements
+                        // [(z / zper) Ng + (z % zper) chunk, ...) and never crosses a call boundary (one call: zper = nsplit, Ng = N)
     unsigned q_mul, ow_mul;   // division by Q = OH*OW and by OW as multiply-high + shifts (see fastdiv)
     int q_s1, q_s2, ow_s1, ow_s2;
     // single-split launches finish in the epilogue (no slab, no reduce kernel):
@@ -1920,9 +1922,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int n_begin = blockIdx.z * p.chunk;
+    const int zgrp = (int)blockIdx.z / p.zper;
+    const int n_begin = zgrp * p.Ng + ((int)blockIdx.z - zgrp * p.zper) * p.chunk;
     int n_end = n_begin + p.chunk;
-    if (n_end > p.N) n_end = p.N;
+    if (n_end > (zgrp + 1) * p.Ng) n_end = (zgrp + 1) * p.Ng;
     const int nl = tid & 31, sub = tid >> 5;   // reduction lane, row/column subgroup (0..7)
     const int Q = p.OH * p.OW;
 
@@ -2073,9 +2076,10 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int n_begin = blockIdx.z * p.chunk;
+    const int zgrp = (int)blockIdx.z / p.zper;
+    const int n_begin = zgrp * p.Ng + ((int)blockIdx.z - zgrp * p.zper) * p.chunk;
     int n_end = n_begin + p.chunk;
-    if (n_end > p.N) n_end = p.N;
+    if (n_end > (zgrp + 1) * p.Ng) n_end = (zgrp + 1) * p.Ng;
 
     // group scales (at most 4 groups) live in registers; gsc = the scale of the pairs currently held in greg[]
     float gs0 = 1.0f, gs1 = 1.0f, gs2 = 1.0f, gs3 = 1.0f, gsc = 1.0f;
@@ -2242,10 +2246,74 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 // out = (sum_z slab[z]) * inv_scale;  partial[block] = this block's share of <sum_z slab[z], w_ref>.
 // ZP = 1: one thread per element walks all slabs.  ZP = 4: four z-groups per element (many slabs, few elements: the
 // 1x1 / attention layers), combined through LDS in a fixed order - results stay bit-reproducible.
+// Stacked calls (groups > 1; the slabs of call k are z = k zper ... (k + 1) zper - 1, each already weighted by 1 / sigma_k):
+// the block emits one partial of <G_k / sigma_k, W_bar> PER CALL (partial[k * nblocks + bid]) - what the spectral-norm backward
+// of stacked calls needs for d(sigma_k), from slab values this pass reads anyway (the activation-side dots <gy_k, y_k - b>
+// it replaces read both activations of every layer once more).
+template <int ZP>
+__device__ __forceinline__ void slab_reduce_groups(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
+                                                   const float* __restrict__ w_ref, double* __restrict__ partial, int bid, int nblocks,
+                                                   int groups, int zper) {
+    __shared__ double gscratch[16];
+    __shared__ float gzsum[4][ZP][256 / ZP];
+    constexpr int EPB = 256 / ZP;
+    const int ex = threadIdx.x % EPB, ez = threadIdx.x / EPB;
+    const int64_t stride = (int64_t)nblocks * EPB;
+    double dot[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i0 = (int64_t)bid * EPB; i0 < n; i0 += stride) {
+        const int64_t i = i0 + ex;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < n) {
+            const float* __restrict__ sp = slab + i;
+            for (int k = 0; k < groups; ++k) {
+                float a = 0.0f;
+                for (int z = ez; z < zper; z += 8 * ZP) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < zper ? sp[(int64_t)(k * zper + z + q * ZP) * n] : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a += v[q];
+                }
+                acc[k] = a;
+            }
+        }
+        if (ZP > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gzsum[k][ez][ex] = acc[k];
+            __syncthreads();
+            if (ez == 0)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < ZP; ++g) a += gzsum[k][g][ex];
+                    acc[k] = a;
+                }
+        }
+        if (ez == 0 && i < n) {
+            const double w = w_ref ? (double)w_ref[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot[k] += (double)acc[k] * w;
+            out[i] = ((acc[0] + acc[1]) + acc[2]) + acc[3];          // calls beyond `groups` contribute + 0.0f: exact
+        }
+    }
+    if (partial) {
+        for (int k = 0; k < groups; ++k) {
+            const double t = block_sum<double>(dot[k], gscratch);
+            if (threadIdx.x == 0) partial[(int64_t)k * nblocks + bid] = t;
+        }
+    }
+}
+
 template <int ZP>
 __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
                                                  const float* __restrict__ w_ref, const float* __restrict__ inv_scale,
-                                                 double* __restrict__ partial, int bid, int nblocks) {
+                                                 double* __restrict__ partial, int bid, int nblocks, int groups = 0, int zper = 0) {
+    if (groups > 1) {
+        slab_reduce_groups<ZP>(slab, out, n, nsplit, w_ref, partial, bid, nblocks, groups, zper);
+        return;
+    }
     __shared__ double scratch[16];
     __shared__ float zsum[ZP][256 / ZP];
     const float sc = inv_scale ? inv_scale[0] : 1.0f;
@@ -2290,8 +2358,9 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab,
 template <int ZP>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
                                                           int nsplit, const float* __restrict__ w_ref,
-                                                          const float* __restrict__ inv_scale, double* __restrict__ partial) {
-    slab_reduce_body<ZP>(slab, out, n, nsplit, w_ref, inv_scale, partial, blockIdx.x, gridDim.x);
+                                                          const float* __restrict__ inv_scale, double* __restrict__ partial,
+                                                          int groups, int zper) {
+    slab_reduce_body<ZP>(slab, out, n, nsplit, w_ref, inv_scale, partial, blockIdx.x, gridDim.x, groups, zper);
 }
 
 // The split reductions of ALL weight gradients of one backward pass in one launch: a weight gradient only feeds a parameter
@@ -2301,7 +2370,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 struct SlabRec {
     const float* slab; float* out; const float* w_ref; const float* inv_scale; double* partial;
     long long n;
-    int nsplit, zp, grid, block0;
+    int nsplit, zp, grid, block0, groups, zper;
 };
 #define SLAB_MAX 32
 struct SlabBatch {
@@ -2314,16 +2383,40 @@ __global__ void __launch_bounds__(256) slab_reduce_batch_kernel(const SlabBatch 
         if ((int)blockIdx.x >= b.r[i].block0) k = i;          // block0 ascending
     const SlabRec& r = b.r[k];
     const int bid = (int)blockIdx.x - r.block0;
-    if (r.zp == 16) slab_reduce_body<16>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
-    else if (r.zp == 4) slab_reduce_body<4>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
-    else slab_reduce_body<1>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid);
+    if (r.zp == 16) slab_reduce_body<16>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid, r.groups, r.zper);
+    else if (r.zp == 4) slab_reduce_body<4>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid, r.groups, r.zper);
+    else slab_reduce_body<1>(r.slab, r.out, r.n, r.nsplit, r.w_ref, r.inv_scale, r.partial, bid, r.grid, r.groups, r.zper);
 }
 
-static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int* tiles_out) {
+// groups > 1 (stacked calls whose per-call <G_k, W_bar> the reduction is to emit): every call's share of the reduction is split on
+// its own - nsplit = groups x zper slabs, none crossing a call boundary, at least one slab per call
+static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int* tiles_out, int groups = 0, int* zper_out = nullptr) {
     *bm = pick_bm(g.M);
     const int R = g.C * g.KH * g.KW;
-    const int64_t N = (int64_t)g.B * g.OH * g.OW;
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
+    if (groups > 1) {
+        const int64_t Ng = (int64_t)(g.B / groups) * g.OH * g.OW;
+        const int64_t max_split = Ng >= 512 ? Ng / 256 : 1;
+        int64_t best_s = 1;
+        double best_cost = 1e300;
+        for (int64_t s_ = 1; s_ <= max_split && s_ * groups <= 512; ++s_) {
+            int64_t ch = (Ng + s_ - 1) / s_;
+            ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
+            const int64_t ns = groups * ((Ng + ch - 1) / ch);
+            const int64_t rounds = (tiles * ns + 767) / 768;
+            const double cost = (double)rounds * (double)ch + 96.0 * (double)ns * (double)tiles / 768.0;
+            if (cost < best_cost * 0.999) { best_cost = cost; best_s = s_; }
+        }
+        int64_t ch = (Ng + best_s - 1) / best_s;
+        ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
+        *chunk = (int)ch;
+        const int zper = (int)((Ng + ch - 1) / ch);
+        *nsplit = groups * zper;
+        if (zper_out) *zper_out = zper;
+        if (tiles_out) *tiles_out = (int)tiles;
+        return;
+    }
+    const int64_t N = (int64_t)g.B * g.OH * g.OW;
     // Split the reduction over s blocks per tile so that the launch fills whole rounds of the 768 resident blocks
     // (256 CUs x 3): cost(s) = rounds(s) x reduction elements per block, plus the slab traffic of s > 1 expressed in
     // the same unit (one output tile written and re-read ~ 96 reduction elements of MFMA time).
@@ -2342,6 +2435,7 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
     *chunk = (int)ch;
     *nsplit = (int)((N + ch - 1) / ch);
+    if (zper_out) *zper_out = *nsplit;
     if (tiles_out) *tiles_out = (int)tiles;
 }
 
@@ -2542,11 +2636,14 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
 
 struct PwPlan {
     bool ok;
-    int tm, tn, tiles_m, tiles_c, steps, chunk, nslab;
+    int tm, tn, tiles_m, tiles_c, steps, chunk, nslab, zper;
 };
 
-static PwPlan pw_plan(const ConvGeom& g) {
+// groups > 1: the slabs are to stay inside one stacked call each (see wgrad_plan); q.zper slabs per call, or q.zper = 0 when the
+// call length does not divide into whole blocks of four wave runs (the caller then takes the dots on the activation side)
+static PwPlan pw_plan(const ConvGeom& g, int groups = 0) {
     PwPlan q;
+    q.zper = 0;
     const long long P = (long long)g.H * g.W;
     q.ok = !path_disabled("pwgrad") && g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H &&
            g.OW == g.W && (P % 8) == 0 && g.M <= 128 && g.C <= 128 && (long long)g.B * P >= 4096 && (long long)g.B * P < (1ll << 31);
@@ -2562,9 +2659,20 @@ static PwPlan pw_plan(const ConvGeom& g) {
     if (waves < 4) waves = 4;
     int chunk = (q.steps + waves - 1) / waves;
     if (chunk < 8) chunk = 8;
+    if (groups > 1 && q.ok) {
+        const long long per = ((long long)(g.B / groups) * P) / 16;          // 16-pixel steps per call
+        if (((long long)(g.B / groups) * P) % 64 != 0) return q;             // zper stays 0
+        while (chunk > 4 && per % (4ll * chunk) != 0) --chunk;
+        if (per % (4ll * chunk) != 0) return q;
+        q.chunk = chunk;
+        q.zper = (int)(per / (4ll * chunk));
+        q.nslab = groups * q.zper;
+        return q;
+    }
     q.chunk = chunk;
     const int nw = (q.steps + chunk - 1) / chunk;
     q.nslab = (nw + 3) / 4;
+    q.zper = q.nslab;
     return q;
 }
 
@@ -2806,6 +2914,36 @@ LOCATE_API int locate_wgrad_batch(const void* records, int n, void* stream) {
     return LOCATE_OK;
 }
 
+// Stacked calls with the per-call <G_k / sigma_k, W_bar> partials out of the split reduction (locate_conv_wgrad with
+// scale_group_batch > 0 AND w_ref + inner_partial): partials PER CALL for this geometry split into `groups` calls - inner_partial
+// then holds groups x that many doubles, [call][partial] - or 0 when this geometry cannot emit them (layers on 1x1 maps / with one
+// output pixel, call lengths that do not divide into whole slabs: take <gy_k, y_k - bias> on the activation side instead,
+// locate_fin_sn_dots).  The workspace of that mode has its own size.
+static bool wgrad_group_dots_ok(const ConvGeom& g, int groups) {
+    if (groups < 2 || groups > 4 || g.B % groups != 0 || skinny_wgrad_ok(g) || onepix_wgrad_ok(g)) return false;
+    const PwPlan q = pw_plan(g, groups);
+    if (q.ok) return q.zper > 0;
+    return (long long)g.B * g.OH * g.OW < (1ll << 31);
+}
+LOCATE_API int locate_conv_wgrad_group_partials(const int* geom, int groups) {
+    const ConvGeom g = make_geom(geom);
+    if (geom_check(g, "locate_conv_wgrad_group_partials") || !wgrad_group_dots_ok(g, groups)) return 0;
+    const PwPlan q = pw_plan(g, groups);
+    if (q.ok) return wgrad_reduce_grid((int64_t)g.M * g.C, q.nslab);
+    int bm, nsplit, chunk, tiles;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles, groups);
+    return wgrad_reduce_grid((int64_t)g.M * g.C * g.KH * g.KW, nsplit);
+}
+LOCATE_API size_t locate_conv_wgrad_group_workspace_bytes(const int* geom, int groups) {
+    const ConvGeom g = make_geom(geom);
+    if (geom_check(g, "locate_conv_wgrad_group_workspace_bytes") || !wgrad_group_dots_ok(g, groups)) return 0;
+    const PwPlan q = pw_plan(g, groups);
+    if (q.ok) return (size_t)q.nslab * g.M * g.C * sizeof(float);
+    int bm, nsplit, chunk, tiles;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles, groups);
+    return (size_t)nsplit * g.M * g.C * g.KH * g.KW * sizeof(float);
+}
+
 // gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw]          (overwritten)
 // With w_ref (= W_bar, same layout as gw) and inner_partial: the partial sums of <UNSCALED gw, W_bar> the
 // spectral-norm backward needs come out of the same pass (locate_conv_wgrad_partials(geom) doubles).
@@ -2825,23 +2963,26 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     LOCATE_REQUIRE(precision != 2 || (x_absmax && gy_absmax), "locate_conv_wgrad: precision 2 needs the absmax words of x and gy");
     LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
     LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
+    // stacked calls with w_ref + inner_partial: the per-call dots come out of the split reduction (locate_conv_wgrad_group_partials)
+    const int gd = (scale_group_batch > 0 && w_ref && inner_partial && g.B % scale_group_batch == 0) ? g.B / scale_group_batch : 0;
     LOCATE_REQUIRE(scale_group_batch >= 0 && (scale_group_batch == 0 || (inv_scale && g.B % scale_group_batch == 0 &&
-                   g.B / scale_group_batch <= 4 && !w_ref && !inner_partial)), "locate_conv_wgrad: bad group scaling arguments");
+                   g.B / scale_group_batch <= 4 && ((!w_ref && !inner_partial) || wgrad_group_dots_ok(g, gd)))),
+                   "locate_conv_wgrad: bad group scaling arguments (per-call partials: see locate_conv_wgrad_group_partials)");
     hipStream_t st = as_stream(stream);
     if (deferred_reduce) memset(deferred_reduce, 0, sizeof(SlabRec));
-    auto reduce = [&](const float* slab, int64_t n, int nsplit, const float* scale, const char* who) -> int {
+    auto reduce = [&](const float* slab, int64_t n, int nsplit, const float* scale, int zper, const char* who) -> int {
         const int rg = wgrad_reduce_grid(n, nsplit);
         const int zp = wgrad_reduce_zp(nsplit, n);
         if (deferred_reduce) {
             SlabRec r;
             r.slab = slab; r.out = gw; r.w_ref = w_ref; r.inv_scale = scale; r.partial = inner_partial;
-            r.n = n; r.nsplit = nsplit; r.zp = zp; r.grid = rg; r.block0 = 0;
+            r.n = n; r.nsplit = nsplit; r.zp = zp; r.grid = rg; r.block0 = 0; r.groups = gd; r.zper = zper;
             memcpy(deferred_reduce, &r, sizeof(r));
             return LOCATE_OK;
         }
-        if (zp == 16) slab_reduce_kernel<16><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
-        else if (zp == 4) slab_reduce_kernel<4><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
-        else slab_reduce_kernel<1><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial);
+        if (zp == 16) slab_reduce_kernel<16><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial, gd, zper);
+        else if (zp == 4) slab_reduce_kernel<4><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial, gd, zper);
+        else slab_reduce_kernel<1><<<rg, 256, 0, st>>>(slab, gw, n, nsplit, w_ref, scale, inner_partial, gd, zper);
         LOCATE_LAUNCH_CHECK(who);
         return LOCATE_OK;
     };
@@ -2858,7 +2999,7 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(one output pixel)");
         return LOCATE_OK;
     }
-    const PwPlan pq = pw_plan(g);
+    const PwPlan pq = pw_plan(g, gd);
     if (pq.ok) {
         // the size queries (workspace bytes, partial count) decide on the geometry alone, so the pointwise plan is binding here:
         // operands it cannot take are an error, never a silent switch to the general plan with its different workspace layout
@@ -2886,16 +3027,17 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
             else pw_wgrad_kernel<2, 2, 3><<<grid, 256, 0, st>>>(q);
         }
         LOCATE_LAUNCH_CHECK("locate_conv_wgrad(pointwise)");
-        return reduce(q.slab, (int64_t)g.M * g.C, pq.nslab, grouped ? nullptr : inv_scale, "locate_conv_wgrad(pointwise reduce)");
+        return reduce(q.slab, (int64_t)g.M * g.C, pq.nslab, grouped ? nullptr : inv_scale, pq.zper, "locate_conv_wgrad(pointwise reduce)");
     }
-    int bm, nsplit, chunk, tiles;
-    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles);
+    int bm, nsplit, chunk, tiles, zper;
+    wgrad_plan(g, &bm, &nsplit, &chunk, &tiles, gd, &zper);
     LOCATE_REQUIRE(nsplit == 1 || workspace, "locate_conv_wgrad: split reduction needs a workspace");
     WgParams p;
     p.x = x; p.gy = gy; p.slab = static_cast<float*>(workspace); p.x_bs = x_bs; p.gy_bs = gy_bs;
     p.B = g.B; p.C = g.C; p.H = g.H; p.W = g.W; p.M = g.M; p.OH = g.OH; p.OW = g.OW; p.KH = g.KH; p.KW = g.KW;
     p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.R = g.C * g.KH * g.KW; p.N = g.B * g.OH * g.OW; p.chunk = chunk;
+    p.zper = zper; p.Ng = gd > 1 ? p.N / gd : p.N;
     fastdiv_make((unsigned)(g.OH * g.OW), &p.q_mul, &p.q_s1, &p.q_s2);
     fastdiv_make((unsigned)g.OW, &p.ow_mul, &p.ow_s1, &p.ow_s2);
     const bool direct = nsplit == 1;
@@ -2933,7 +3075,7 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     else if (bm == 64) conv_wgrad_kernel<1, 4, 2, 1><<<grid, 256, 0, st>>>(p);
     else conv_wgrad_kernel<1, 4, 1, 1><<<grid, 256, 0, st>>>(p);
     LOCATE_LAUNCH_CHECK("locate_conv_wgrad(gemm)");
-    if (!direct) return reduce(p.slab, (int64_t)g.M * p.R, nsplit, grouped ? nullptr : inv_scale, "locate_conv_wgrad(reduce)");
+    if (!direct) return reduce(p.slab, (int64_t)g.M * p.R, nsplit, grouped ? nullptr : inv_scale, zper, "locate_conv_wgrad(reduce)");
     return LOCATE_OK;
 }
 

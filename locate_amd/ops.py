@@ -1201,7 +1201,7 @@ def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0,
 
 
 def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0, amax_in=None, amax_out=None,
-                     rt=None):
+                     rt=None, group_dots=0):
     """gw = (sum over the batch of R's input x R's output gradient) / sigma, plus the partial sums of <G, W_bar>.
     With a runtime that defers its finalisers, the layers on 1x1 maps / with one output pixel are only queued: one launch for
     all of them at the end of the pass (Runtime.queue_small_wgrad)."""
@@ -1214,7 +1214,8 @@ def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst
             rt.queue_small_wgrad(rec.raw, (xin, gout, gw, w_ref, inv_sigma, partial))
             return
     if spec.mode == "dense":
-        nbytes = L.locate_conv_wgrad_workspace_bytes(garr)
+        # group_dots: stacked calls with the per-call <G_k, W_bar> partials out of the split reduction (its own slab layout)
+        nbytes = L.locate_conv_wgrad_group_workspace_bytes(garr, group_dots) if group_dots else L.locate_conv_wgrad_workspace_bytes(garr)
         defer = rt is not None and rt.defer_finalisers and nbytes > 0
         # a deferred split reduction reads its slab at the end of the pass: the layer gets a slab of its own instead of the
         # shared scratch buffer
@@ -1265,6 +1266,15 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
+        npg = L.locate_conv_wgrad_group_partials(garr, groups) if (rt.defer_finalisers and spec.mode == "dense") else 0
+        if npg > 0:
+            # d(sigma_k) from the WEIGHT side: the split reduction's slabs never cross a call boundary, so its pass over them also
+            # yields <G_k / sigma_k, W_bar> per call - the value of <gy_k, y_k - bias> without reading gy and y again
+            partial = torch.empty(groups * npg, dtype=torch.float64, device=x.device)
+            _raw_weight_grad(spec, geom, garr, xin, gout, gw, w, inv_sigma, sbg, sst, partial, rt.precision, am_in, am_out, rt, groups)
+            dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
+            rt.queue_sn_rank1(partial, npg, groups, sigma, sigma.stride(0), u, v, wv, wv.stride(0), gw, gu, dsig, h, wd)
+            return gw, gu
         _raw_weight_grad(spec, geom, garr, xin, gout, gw, None, inv_sigma, sbg, sst, None, rt.precision, am_in, am_out, rt)
         dsig = rt.defer_dv(v_param, u_param, w, h, wd) if need_v else None
         Bn, Mn = gy.shape[0], gy.shape[1]

@@ -1071,3 +1071,49 @@ def test_deferred_split_reductions_equal_immediate_ones():
     torch.cuda.synchronize()
     for (g1, p1), (g2, p2) in pending:
         assert torch.equal(g1, g2) and torch.equal(p1, p2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,k,s,p,cin,cout,H,Bg,groups", [("conv", 5, 2, 2, 16, 16, 16, 8, 3), ("conv", 1, 1, 0, 3, 29, 32, 8, 3),
+                                                              ("conv", 1, 1, 0, 64, 64, 8, 16, 3), ("conv", 3, 1, 1, 12, 20, 6, 4, 2),
+                                                              ("conv", 5, 2, 2, 8, 8, 7, 3, 3), ("convT", 4, 2, 1, 8, 8, 4, 4, 4)])
+def test_weight_side_group_dots(kind, k, s, p, cin, cout, H, Bg, groups):
+    """Stacked calls: the split reduction of the weight gradient, laid out call by call, emits <G_k / sigma_k, W_bar> per call -
+    against float64: the per-call dots equal <gy_k, y_k> of y = conv(x, W_bar) / sigma_k (what locate_fin_sn_dots reads off the
+    activations), and gw = sum_k G_k / sigma_k as without them."""
+    import ctypes
+    from locate_amd import ops
+    from locate_amd._lib import check, lib
+    L = lib()
+    torch.manual_seed(groups * 100 + cin)
+    st = torch.cuda.current_stream().cuda_stream
+    B = Bg * groups
+    spec = ops.ConvSpec(kind, k, k, s, p, p)
+    x = torch.randn(B, cin, H, H, device=dev())
+    w = torch.randn((cout, cin, k, k) if kind == "conv" else (cin, cout, k, k), device=dev())
+    geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+    garr = (ctypes.c_int * 12)(*geom)
+    gy = torch.randn(out_shape, device=dev())
+    sig = torch.tensor([1.3, 0.7, 2.1, 0.9][:groups], device=dev())
+    inv = (1.0 / sig).contiguous()
+    npg = L.locate_conv_wgrad_group_partials(garr, groups)
+    assert npg > 0
+    part = torch.zeros(groups * npg, dtype=torch.float64, device=dev())
+    ws = torch.empty(max(L.locate_conv_wgrad_group_workspace_bytes(garr, groups), 16), dtype=torch.uint8, device=dev())
+    gw = torch.empty_like(w)
+    xin, gout = (x, gy) if kind == "conv" else (gy, x)
+    check(L.locate_conv_wgrad(garr, xin.data_ptr(), xin.stride(0), gout.data_ptr(), gout.stride(0), gw.data_ptr(), w.data_ptr(), inv.data_ptr(),
+                              Bg, 1, part.data_ptr(), ws.data_ptr(), 0, None, None, None, st), "locate_conv_wgrad")
+    torch.cuda.synchronize()
+    xd, wd, gd = x.double().cpu(), w.double().cpu(), gy.double().cpu()
+    gw_ref = torch.zeros_like(wd)
+    for kk in range(groups):
+        sl = slice(kk * Bg, (kk + 1) * Bg)
+        wr = wd.clone().requires_grad_(True)
+        y = (F.conv2d(xd[sl], wr, None, s, p) if kind == "conv" else F.conv_transpose2d(xd[sl], wr, None, s, p)) / float(sig[kk])
+        y.backward(gd[sl])
+        gw_ref += wr.grad
+        dot_ref = float((gd[sl] * y.detach()).sum())
+        got = float(part[kk * npg:(kk + 1) * npg].sum())
+        assert abs(got - dot_ref) <= 2e-5 * float((gd[sl] * y.detach()).abs().sum()), (kk, got, dot_ref)
+    assert_close(gw.cpu().double(), gw_ref, 2e-5, "gw")
