@@ -2264,17 +2264,22 @@ __device__ __forceinline__ void slab_reduce_groups(const float* __restrict__ sla
         const int64_t i = i0 + ex;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (i < n) {
+            // z walks ALL slabs, call-major, eight loads in flight; slab z belongs to call z / zper and is added to that call's sum
+            // (the other calls' sums take + 0.0f: exact), in z order within each call
             const float* __restrict__ sp = slab + i;
-            for (int k = 0; k < groups; ++k) {
-                float a = 0.0f;
-                for (int z = ez; z < zper; z += 8 * ZP) {
-                    float v[8];
+            for (int z = ez; z < nsplit; z += 8 * ZP) {
+                float v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < zper ? sp[(int64_t)(k * zper + z + q * ZP) * n] : 0.0f;
+                for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < nsplit ? sp[(int64_t)(z + q * ZP) * n] : 0.0f;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a += v[q];
+                for (int q = 0; q < 8; ++q) {
+                    const int zz = z + q * ZP;
+                    const int k = (zz >= zper) + (zz >= 2 * zper) + (zz >= 3 * zper);
+                    acc[0] += k == 0 ? v[q] : 0.0f;
+                    acc[1] += k == 1 ? v[q] : 0.0f;
+                    acc[2] += k == 2 ? v[q] : 0.0f;
+                    acc[3] += k == 3 ? v[q] : 0.0f;
                 }
-                acc[k] = a;
             }
         }
         if (ZP > 1) {
@@ -2695,6 +2700,45 @@ struct OnePix {
 static inline int skw_mt(int M) { return M >= SKW_WIDE_M ? SKW_MT_WIDE : SKW_MT; }
 #define SKW_NC 32         // batch rows per load batch
 
+// one finished element (row m, column j) of the gradient: scattered to its tap for a one-pixel layer; its <G, W_bar> term
+__device__ __forceinline__ void skw_store(const OnePix& op, float* __restrict__ gw, const float* __restrict__ w_ref, int C, int m, int j,
+                                          float v, float sc, double& dot) {
+    long long o = (long long)m * C + j;
+    bool inside = true;
+    if (op.hw > 0) {           // column j = (c, iy, ix) of a whole input map: tap (iy + pad_h, ix + pad_w) of weight row (m, c)
+        const int c = j / op.hw, pix = j - c * op.hw;
+        const int iy = pix / op.W, ix = pix - iy * op.W;
+        const int kh = iy + op.pad_h, kw = ix + op.pad_w;
+        inside = kh < op.KH && kw < op.KW;           // pixels no tap of the single output position reaches
+        o = (((long long)m * op.Cw + c) * op.KH + kh) * op.KW + kw;
+    }
+    if (inside) {
+        if (w_ref) dot += (double)v * (double)w_ref[o];
+        gw[o] = v * sc;
+    }
+}
+
+// The taps no input pixel reaches get their zeros here: the block owns rows i0 .. i0 + mt - 1 of the channels its 64 columns
+// span - contiguous runs of gw - and walks them with consecutive lanes on consecutive addresses, skipping the taps skw_store
+// wrote (disjoint addresses: no ordering needed).  A channel whose pixels straddle two blocks is zeroed by the block that
+// holds its pixel 0.
+__device__ __forceinline__ void skw_zero_taps(const OnePix& op, float* __restrict__ gw, int M, int i0, int mt, int bx) {
+    const int H = op.hw / op.W, taps = op.KH * op.KW;
+    const int first_col = bx * 64;
+    const int c_first = (first_col + op.hw - 1) / op.hw;
+    int c_last = (first_col + 63) / op.hw;
+    if (c_last > op.Cw - 1) c_last = op.Cw - 1;
+    const int span = (c_last - c_first + 1) * taps;
+    for (int t = 0; t < mt; ++t) {
+        if (i0 + t >= M) break;
+        float* row = gw + ((long long)(i0 + t) * op.Cw + c_first) * taps;
+        for (int e = threadIdx.x; e < span; e += blockDim.x) {
+            const int tap = e % taps, kh = tap / op.KW, kw = tap - kh * op.KW;
+            if (!(kh >= op.pad_h && kh - op.pad_h < H && kw >= op.pad_w && kw - op.pad_w < op.W)) row[e] = 0.0f;
+        }
+    }
+}
+
 template <int MT>
 __device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
                                                   long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
@@ -2743,43 +2787,75 @@ __device__ __forceinline__ void skinny_wgrad_body(const float* __restrict__ x, l
         const int t = wid * (MT / 4) + q;
         if (jok && i0 + t < M) {
             const float v = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
-            long long o = (long long)(i0 + t) * C + j;
-            bool inside = true;
-            if (op.hw > 0) {           // column j = (c, iy, ix) of a whole input map: tap (iy + pad_h, ix + pad_w) of weight row (m, c)
-                const int c = j / op.hw, pix = j - c * op.hw;
-                const int iy = pix / op.W, ix = pix - iy * op.W;
-                const int kh = iy + op.pad_h, kw = ix + op.pad_w;
-                inside = kh < op.KH && kw < op.KW;           // pixels no tap of the single output position reaches
-                o = (((long long)(i0 + t) * op.Cw + c) * op.KH + kh) * op.KW + kw;
-            }
-            if (inside) {
-                if (w_ref) dot += (double)v * (double)w_ref[o];
-                gw[o] = v * sc;
-            }
+            skw_store(op, gw, w_ref, C, i0 + t, j, v, sc, dot);
         }
     }
-    if (op.hw > 0) {
-        // the taps no input pixel reaches get their zeros here: the block owns rows i0 .. i0 + 7 of the channels its 64 columns
-        // span - contiguous runs of gw - and walks them with consecutive lanes on consecutive addresses, skipping the taps the
-        // code above wrote (disjoint addresses: no ordering needed).  A channel whose pixels straddle two blocks is zeroed by
-        // the block that holds its pixel 0.
-        const int H = op.hw / op.W, taps = op.KH * op.KW;
-        const int first_col = bx * 64;
-        const int c_first = (first_col + op.hw - 1) / op.hw;
-        int c_last = (first_col + 63) / op.hw;
-        if (c_last > op.Cw - 1) c_last = op.Cw - 1;
-        const int span = (c_last - c_first + 1) * taps;
-        for (int t = 0; t < MT; ++t) {
-            if (i0 + t >= M) break;
-            float* row = gw + ((long long)(i0 + t) * op.Cw + c_first) * taps;
-            for (int e = threadIdx.x; e < span; e += blockDim.x) {
-                const int tap = e % taps, kh = tap / op.KW, kw = tap - kh * op.KW;
-                if (!(kh >= op.pad_h && kh - op.pad_h < H && kw >= op.pad_w && kw - op.pad_w < op.W)) row[e] = 0.0f;
-            }
-        }
-    }
+    if (op.hw > 0) skw_zero_taps(op, gw, M, i0, MT, bx);
     if (partial) {
         dot = block_sum<double>(dot, scratch);
+        if (threadIdx.x == 0) partial[by * grid_x + bx] = dot;
+    }
+}
+
+// Layers of SKW_WIDE_M rows or more: a 32 x 64 tile of the gradient per block, both operands staged through LDS in runs of
+// SKW_WN batch rows with coalesced loads (the narrow form's per-row scalar loads of gy cost a round trip per batch row and block),
+// 2 x 4 results per thread, the batch rows summed in order by ONE thread per result (no cross-wave combination).
+#define SKW_WN 96
+__device__ __forceinline__ void skinny_wgrad_wide(const float* __restrict__ x, long long x_bs, const float* __restrict__ gy,
+                                                  long long gy_bs, float* __restrict__ gw, const float* __restrict__ w_ref,
+                                                  const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
+                                                  double* __restrict__ partial, int N, int M, int C, const OnePix& op, int bx, int by,
+                                                  int grid_x) {
+    __shared__ double wscratch[16];
+    __shared__ float gs[SKW_WN][SKW_MT_WIDE];
+    __shared__ float xs[SKW_WN][64];
+    const int tid = threadIdx.x;
+    const int i0 = by * SKW_MT_WIDE, j0 = bx * 64;
+    const int tm = tid >> 4, tc = tid & 15;              // rows i0 + 2 tm + {0, 1}, columns j0 + 4 tc + {0 .. 3}
+    const int gm = tid & 31, gr = tid >> 5;              // staging: gy column / first row of this thread
+    const int xc = tid & 63, xr = tid >> 6;
+    const bool gok = i0 + gm < M, xok = j0 + xc < C;
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int n0 = 0; n0 < N; n0 += SKW_WN) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SKW_WN / 8; ++r) {
+            const int n = n0 + gr + 8 * r;
+            float v = 0.0f;
+            if (gok && n < N) {
+                v = gy[(long long)n * gy_bs + i0 + gm];
+                if (scale_bg) v *= inv_scale[(n / scale_bg) * scale_stride];
+            }
+            gs[gr + 8 * r][gm] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < SKW_WN / 4; ++r) {
+            const int n = n0 + xr + 4 * r;
+            xs[xr + 4 * r][xc] = (xok && n < N) ? x[(long long)n * x_bs + j0 + xc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < SKW_WN; ++k) {
+            const float2 g = *reinterpret_cast<const float2*>(&gs[k][2 * tm]);
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[k][4 * tc]);
+            acc[0][0] = fmaf(g.x, xv.x, acc[0][0]); acc[0][1] = fmaf(g.x, xv.y, acc[0][1]);
+            acc[0][2] = fmaf(g.x, xv.z, acc[0][2]); acc[0][3] = fmaf(g.x, xv.w, acc[0][3]);
+            acc[1][0] = fmaf(g.y, xv.x, acc[1][0]); acc[1][1] = fmaf(g.y, xv.y, acc[1][1]);
+            acc[1][2] = fmaf(g.y, xv.z, acc[1][2]); acc[1][3] = fmaf(g.y, xv.w, acc[1][3]);
+        }
+    }
+    const float sc = (!scale_bg && inv_scale) ? inv_scale[0] : 1.0f;
+    double dot = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = i0 + 2 * tm + a, j = j0 + 4 * tc + b;
+            if (m < M && j < C) skw_store(op, gw, w_ref, C, m, j, acc[a][b], sc, dot);
+        }
+    if (op.hw > 0) skw_zero_taps(op, gw, M, i0, SKW_MT_WIDE, bx);
+    if (partial) {
+        dot = block_sum<double>(dot, wscratch);
         if (threadIdx.x == 0) partial[by * grid_x + bx] = dot;
     }
 }
@@ -2789,8 +2865,8 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restri
                                                            const float* __restrict__ inv_scale, int scale_bg, int scale_stride,
                                                            double* __restrict__ partial, int N, int M, int C, OnePix op) {
     if (M >= SKW_WIDE_M)
-        skinny_wgrad_body<SKW_MT_WIDE>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x,
-                                       blockIdx.y, gridDim.x);
+        skinny_wgrad_wide(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x, blockIdx.y,
+                          gridDim.x);
     else
         skinny_wgrad_body<SKW_MT>(x, x_bs, gy, gy_bs, gw, w_ref, inv_scale, scale_bg, scale_stride, partial, N, M, C, op, blockIdx.x,
                                   blockIdx.y, gridDim.x);
@@ -2820,8 +2896,8 @@ __global__ void __launch_bounds__(256) skinny_wgrad_batch_kernel(const SkwBatch 
     const int local = (int)blockIdx.x - r.block0;
     const int by = local / r.grid_x, bx = local - by * r.grid_x;
     if (r.M >= SKW_WIDE_M)
-        skinny_wgrad_body<SKW_MT_WIDE>(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N,
-                                       r.M, r.C, r.op, bx, by, r.grid_x);
+        skinny_wgrad_wide(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N, r.M, r.C,
+                          r.op, bx, by, r.grid_x);
     else
         skinny_wgrad_body<SKW_MT>(r.x, r.x_bs, r.gy, r.gy_bs, r.gw, r.w_ref, r.inv_scale, r.scale_bg, r.scale_stride, r.partial, r.N, r.M,
                                   r.C, r.op, bx, by, r.grid_x);
