@@ -2807,8 +2807,9 @@ __device__ __forceinline__ void skinny_wgrad_wide(const float* __restrict__ x, l
                                                   double* __restrict__ partial, int N, int M, int C, const OnePix& op, int bx, int by,
                                                   int grid_x) {
     __shared__ double wscratch[16];
-    __shared__ float gs[SKW_WN][SKW_MT_WIDE];
-    __shared__ float xs[SKW_WN][64];
+    __shared__ __attribute__((aligned(16))) float wbuf[SKW_WN * (SKW_MT_WIDE + 64)];          // operand stages, then the output rows of a one-pixel layer
+    float (*gs)[SKW_MT_WIDE] = reinterpret_cast<float (*)[SKW_MT_WIDE]>(wbuf);
+    float (*xs)[64] = reinterpret_cast<float (*)[64]>(wbuf + SKW_WN * SKW_MT_WIDE);
     const int tid = threadIdx.x;
     const int i0 = by * SKW_MT_WIDE, j0 = bx * 64;
     const int tm = tid >> 4, tc = tid & 15;              // rows i0 + 2 tm + {0, 1}, columns j0 + 4 tc + {0 .. 3}
@@ -2846,14 +2847,63 @@ __device__ __forceinline__ void skinny_wgrad_wide(const float* __restrict__ x, l
     }
     const float sc = (!scale_bg && inv_scale) ? inv_scale[0] : 1.0f;
     double dot = 0.0;
+    const int taps = op.KH * op.KW;
+    // One-pixel layer whose 64 columns are whole channels (hw | 64) and whose weight rows take 16-byte stores: the block's output
+    // - 64 / hw channels x taps floats per row, contiguous in gw - is assembled in LDS (zeros, then the useful taps scattered in)
+    // and streamed out with full-width stores, a few rows per pass: scattered 4-byte stores plus a separate zeroing walk cost
+    // more than the arithmetic (26 MB of D's last 5x5 layer: 61 -> measured below).
+    const int cpb = op.hw > 0 && (64 % op.hw) == 0 ? 64 / op.hw : 0;
+    const int c0 = bx * cpb;
+    const int nch = cpb > 0 ? (c0 + cpb <= op.Cw ? cpb : op.Cw - c0) : 0;
+    const int rowlen = nch * taps;
+    const bool staged = cpb > 0 && nch > 0 && (rowlen & 3) == 0 && (((long long)op.Cw * taps) & 3) == 0 && (((long long)c0 * taps) & 3) == 0 &&
+                        rowlen * 2 <= SKW_WN * (SKW_MT_WIDE + 64) && (reinterpret_cast<uintptr_t>(gw) & 15) == 0;
+    if (staged) {
+        int rpp = (SKW_WN * (SKW_MT_WIDE + 64)) / rowlen;          // rows per pass: even (a thread's two rows stay together)
+        rpp = rpp > SKW_MT_WIDE ? SKW_MT_WIDE : (rpp & ~1);
+        const DivU32 dq((unsigned)(rowlen / 4));
+        for (int r0 = 0; r0 < SKW_MT_WIDE && i0 + r0 < M; r0 += rpp) {
+            __syncthreads();
+            for (int e = tid; e < rpp * rowlen / 4; e += 256) reinterpret_cast<float4*>(wbuf)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a) {
+                const int row = 2 * tm + a;
+                if (row >= r0 && row < r0 + rpp && i0 + row < M) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = i0 + 2 * tm + a, j = j0 + 4 * tc + b;
-            if (m < M && j < C) skw_store(op, gw, w_ref, C, m, j, acc[a][b], sc, dot);
+                    for (int b = 0; b < 4; ++b) {
+                        const int jl = 4 * tc + b, cl = jl / op.hw, pix = jl - cl * op.hw;
+                        const int iy = pix / op.W, ix = pix - iy * op.W;
+                        const int kh = iy + op.pad_h, kw = ix + op.pad_w;
+                        if (cl < nch && kh < op.KH && kw < op.KW) {
+                            const int t = cl * taps + kh * op.KW + kw;
+                            const float v = acc[a][b];
+                            if (w_ref) dot += (double)v * (double)w_ref[((long long)(i0 + row) * op.Cw + c0) * taps + t];
+                            wbuf[(row - r0) * rowlen + t] = v * sc;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            int rows = M - (i0 + r0);
+            if (rows > rpp) rows = rpp;
+            if (rows > SKW_MT_WIDE - r0) rows = SKW_MT_WIDE - r0;
+            for (int e = tid; e < rows * rowlen / 4; e += 256) {
+                unsigned r, q;
+                dq.divmod((unsigned)e, r, q);
+                reinterpret_cast<float4*>(gw + ((long long)(i0 + r0 + (int)r) * op.Cw + c0) * taps)[q] = reinterpret_cast<const float4*>(wbuf)[e];
+            }
         }
-    if (op.hw > 0) skw_zero_taps(op, gw, M, i0, SKW_MT_WIDE, bx);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = i0 + 2 * tm + a, j = j0 + 4 * tc + b;
+                if (m < M && j < C) skw_store(op, gw, w_ref, C, m, j, acc[a][b], sc, dot);
+            }
+        if (op.hw > 0) skw_zero_taps(op, gw, M, i0, SKW_MT_WIDE, bx);
+    }
     if (partial) {
         dot = block_sum<double>(dot, wscratch);
         if (threadIdx.x == 0) partial[by * grid_x + bx] = dot;

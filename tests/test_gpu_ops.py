@@ -305,6 +305,10 @@ CONV_CASES = [
     ("conv", 768, 12, 1, 1, 0, 192, 1, 1),    # batch 192
     ("conv", 16, 16, 5, 2, 2, 3, 3, 3),       # 3x3 -> 2x2: 4 of 5 rows / columns
     ("convT", 32, 32, 4, 2, 1, 3, 1, 1),      # transposed 1x1 -> 2x2: one tap per sub-pixel phase
+    ("conv", 24, 160, 5, 2, 2, 6, 2, 2),      # one output pixel, 128+ rows: weight gradient through LDS tiles, rows assembled in LDS
+    ("conv", 40, 136, 3, 1, 1, 5, 1, 1),      # ... the head's shape (one useful tap of nine)
+    ("conv", 16, 130, 4, 2, 1, 4, 3, 3),      # ... a 3x3 map (9 pixels: not whole channels per 64 columns - scattered stores)
+    ("conv", 200, 144, 1, 1, 0, 7, 1, 1),     # 1x1 map, 128+ rows
     ("conv", 8, 8, 5, 2, 2, 2, 1, 5),         # 1 x 5 map: one useful row, all five columns
     # tall 192 x 128 tiles (M a multiple of 192 and >= 512 tiles): adjoint phases and the regular direction
     ("convT", 192, 192, 4, 2, 1, 64, 16, 16),
@@ -994,7 +998,8 @@ def test_small_weight_gradients_batched_equal_single_launches():
     torch.manual_seed(2)
     st = torch.cuda.current_stream().cuda_stream
     cases = [("conv", 1, 1, 1, 0, 24, 40, 1, 64), ("conv", 1, 1, 1, 0, 832, 384, 1, 64), ("conv", 5, 5, 2, 2, 16, 16, 2, 12),
-             ("conv", 3, 3, 1, 1, 32, 8, 1, 6), ("conv", 1, 1, 1, 0, 7, 3, 1, 5)]
+             ("conv", 3, 3, 1, 1, 32, 8, 1, 6), ("conv", 1, 1, 1, 0, 7, 3, 1, 5), ("conv", 5, 5, 2, 2, 32, 160, 2, 12),
+             ("conv", 3, 3, 1, 1, 64, 136, 1, 6), ("conv", 4, 4, 2, 1, 16, 130, 3, 4)]
     recs, expect, outs, keep = [], [], [], []
     for kind, kh, kw, s, p, cin, cout, H, B in cases:
         spec = ops.ConvSpec(kind, kh, kw, s, p, p)
