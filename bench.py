@@ -41,10 +41,14 @@ def parse():
                     help="run the three discriminator passes of the D-step on three streams (measured: no gain under "
                          "hipGraph replay on ROCm 7.0 - parallel branches are replayed almost serially)")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--no-wgrad-overlap", action="store_true",
-                    help="weight gradients in line with the backward pass (default, at any N: on a second stream beside it; same "
-                         "values, -0.25 ms per step; the data-parallel reducer picks such gradients up at the end of the pass - "
-                         "tests/test_gpu_dp.py)")
+    ap.add_argument("--wgrad-overlap", choices=("auto", "on", "off"), default="auto",
+                    help="weight gradients on a second stream beside the backward pass's chain of input gradients (same values; the "
+                         "data-parallel reducer picks such gradients up at the end of the pass - tests/test_gpu_dp.py).  auto: off on "
+                         "one GPU - since the small weight gradients and all split reductions of a pass run as two batched launches at "
+                         "its end, the ~60 forks into the second stream cost more than the concurrency returns (same-box A/B, "
+                         "profiles/r03_wgrad_overlap_ab.txt: 9.88 -> 9.72 ms) - and on in the data-parallel mode, whose reducer hooks "
+                         "keep the per-layer finalisers")
+    ap.add_argument("--no-wgrad-overlap", action="store_true", help="same as --wgrad-overlap off")
     ap.add_argument("--f16-min-gflop", type=float, default=None,
                     help="work threshold (GFLOP per launch) above which a fp32-faithful contraction takes its fp16-piece form "
                          "(default: locate_amd.ops.F16_MIN_FLOPS); a huge value turns the form off")
@@ -317,8 +321,9 @@ def main():
         d_cut = 3 if len(D.main[1].blocks) > 3 else None
         red_g = GradAllReducer(G.parameters(), force=force_dp)
         red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp)
+    wgrad_overlap = False if (args.no_wgrad_overlap or args.wgrad_overlap == "off") else (True if args.wgrad_overlap == "on" else bool(dp))
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
-                     overlap_wgrad=not args.no_wgrad_overlap, d_cut=d_cut)
+                     overlap_wgrad=wgrad_overlap, d_cut=d_cut)
     B, S = args.batch, args.image_size
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     latent = torch.randn(B, S, generator=gen).to(dev)

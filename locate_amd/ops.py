@@ -6,6 +6,7 @@ spectral-normalised convolutions (libs/spectral_norm.py:57-59 + the wrapped torc
 PyTorch is used for device memory, streams and the autograd graph only - no ATen arithmetic on the hot path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -231,6 +232,7 @@ class Runtime:
         self.precision = 0               # contractions: 0 = fp32-faithful (the reference's arithmetic), 1 = bf16 operands
         self.stacked = 1                 # forward: the batch holds this many independent calls (main.py:149-152 as one pass)
         self.weight_grad_stream = None   # backward: weight gradients are launched on this stream (None: in line)
+        self.weight_grad_side_min_flops = float(os.environ.get("LOCATE_WGRAD_SIDE_MIN_GFLOP", "0")) * 1e9
         self._dv_layers = {}             # id(v) -> (v, u, w, h, wd, state): layers whose dv is still to be finalised
         self._dv_tables = {}             # tuple of addresses -> (device table, max_h, max_wd)
         self._end_scheduled = False
@@ -1413,6 +1415,8 @@ class SNConvFn(torch.autograd.Function):
         if need_w or need_u or need_v:
             rt = ctx.rt
             side = rt.weight_grad_stream
+            if side is not None and spec.mode == "dense" and _flops(ctx.geom) < rt.weight_grad_side_min_flops:
+                side = None              # a fork into the second stream costs more than a small launch gains there
             late = side is not None or rt.defer_finalisers     # the gradients bypass autograd: assigned at the end of the pass
             if side is None:
                 sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v,
