@@ -51,11 +51,15 @@ class GraphedTrainStep:
 
         cap_stream = torch.cuda.Stream()     # ONE capture stream: autograd replays a node's backward on its forward's stream
         self.pool_b = torch.cuda.graph_pool_handle()
-        self._side = torch.cuda.Stream()
-        self._e0, self._e1, self._e2, self._es = (torch.cuda.Event() for _ in range(4))
+        import os
+        self.early_second_pass = os.environ.get("LOCATE_G2_EARLY", "0") == "1"
+        prio = os.environ.get("LOCATE_SIDE_PRIORITY")
+        self._side = torch.cuda.Stream(priority=int(prio)) if prio is not None else torch.cuda.Stream()
+        self._e0, self._e1, self._e2, self._es, self._eb = (torch.cuda.Event() for _ in range(5))
         self._keep = []
         self.sn_graph = None
         self.d_tail = None
+        self.begin_graph = None
 
         # With a process group alive its watchdog thread polls the events of earlier collectives (hipEventQuery) at any time;
         # under the default "global" capture mode that call, made by ANOTHER thread while this one captures, is an error that
@@ -82,6 +86,21 @@ class GraphedTrainStep:
         step.reducer_d = step.reducer_g = None
         try:
             if self.overlap:
+                # LOCATE_G2_EARLY=1 (experiment, off by default: measured +0.10 ... +0.15 ms per step, same-box A/B in
+                # profiles/r03_two_generator_passes_ab.txt).  Ahead of both generator passes: the iteration's zeroed absmax
+                # block and G's two power iterations (a small graph of its own).  The two passes then depend on nothing of each
+                # other and are replayed CONCURRENTLY - the G-step's pass on the second stream from the start of the iteration
+                # instead of after the D-step's pass.  The second pass's contractions take their own split-K arrival counters
+                # (ops.counter_lane).  Bit-identical results (test_graph_replay_equals_eager passes either way); slower because
+                # the D-step's pass is on the critical path and loses more to the contention than the later overlap with the
+                # discriminator work gives back.
+                self.begin_graph = None
+                if self.early_second_pass and getattr(step.gen, "batched_spectral_norm", False) and step.minibatches == 1:
+                    self.begin_graph = torch.cuda.CUDAGraph()
+                    with graph_ctx(self.begin_graph, self.pool):
+                        step.begin_iteration(lat.device)
+                    from . import ops as _ops
+                    self._keep.append(_ops.AMAX.block)
                 generated = capture(lambda: step.d_generate(lat))                              # 0
                 # The discriminator's three power iterations of the D-step (sigma for real / fake / augmented, main.py:149-152)
                 # read only what the PREVIOUS iteration left behind (D's weights after its optimizer step, u / v after the
@@ -103,7 +122,12 @@ class GraphedTrainStep:
                     capture(lambda: step.d_forward_backward(lat, real_, aug_, generated=generated))  # 1
                 self._prime(step.dis_opt)
                 capture(step.d_optimizer)                                                      # 2
-                fake = capture(lambda: step.g_forward(lat), pool=self.pool_b)                  # 3 (second stream)
+                if self.begin_graph is not None:
+                    from . import ops as _ops
+                    with _ops.counter_lane(1):
+                        fake = capture(lambda: step.g_forward(lat), pool=self.pool_b)          # 3 (second stream)
+                else:
+                    fake = capture(lambda: step.g_forward(lat), pool=self.pool_b)              # 3 (second stream)
                 capture(lambda: step.g_backward(fake))                                         # 4
                 self._prime(step.gen_opt)
                 capture(step.g_optimizer)                                                      # 5
@@ -135,6 +159,9 @@ class GraphedTrainStep:
             main = torch.cuda.current_stream()
             g = self.graphs
             self._e0.record(main)                  # everything the previous iteration wrote is complete here
+            if self.begin_graph is not None:
+                self.begin_graph.replay()          # absmax block zeroed, G's two power iterations queued
+            self._eb.record(main)
             g[0].replay()                          # D-step generator pass
             self._e1.record(main)
             with torch.cuda.stream(self._side):
@@ -142,8 +169,10 @@ class GraphedTrainStep:
                     self._side.wait_event(self._e0)
                     self.sn_graph.replay()         # D's three power iterations, beside the generator pass
                     self._es.record(self._side)
-                self._side.wait_event(self._e1)
-                g[3].replay()                      # G-step generator pass, concurrent with the discriminator work below
+                # the G-step's generator pass: beside the D-step's one when both only consume queued power iterations, else
+                # behind it (its own power iteration continues the first pass's)
+                self._side.wait_event(self._eb if (self.begin_graph is not None and self.early_second_pass) else self._e1)
+                g[3].replay()                      # ... and concurrent with the discriminator work below
                 self._e2.record(self._side)
             if self.sn_graph is not None:
                 main.wait_event(self._es)

@@ -74,10 +74,19 @@ class _AmaxArena:
         if not self._step:
             self.block = None
 
-    def new_step(self):
-        """A training iteration begins (TrainStep.d_generate): ONE block serves all its passes."""
-        self.block = None
-        self._step = True
+    def new_step(self, device=None):
+        """A training iteration begins (TrainStep.begin_iteration / d_generate): ONE block serves all its passes.  Idempotent
+        until end_step().  With a device the zeroed block is created NOW - before passes of the iteration that may run
+        concurrently (two generator passes on two streams) publish into it."""
+        if not self._step:
+            self.block = None
+            self._step = True
+        if device is not None and self.enabled and (self.block is None or self.block.device != device):
+            if self.words is None:
+                self.words = lib().locate_absmax_words()
+            self.cap = self.STEP_SLOTS
+            self.block = torch.zeros(self.cap * self.words, dtype=torch.int32, device=device)
+            self.used = 0
 
     def end_step(self):
         self._step = False
@@ -1104,6 +1113,25 @@ def _sigma_args(sigma, batch):
     return groups, batch // groups, sigma.stride(0), sigma[0, 1:]
 
 
+_COUNTER_LANE = [0]
+
+
+class counter_lane:
+    """with counter_lane(1): the contractions launched (or captured) inside take a second set of split-K arrival counters.
+    The same LAYER may then run twice at once - the two generator passes of one iteration on two streams (graph.py) - without
+    the two launches sharing a counter block.  The lane's blocks are created by the eager iterations like all others."""
+
+    def __init__(self, lane):
+        self.lane = int(lane)
+
+    def __enter__(self):
+        self.prev = _COUNTER_LANE[0]
+        _COUNTER_LANE[0] = self.lane
+
+    def __exit__(self, *exc):
+        _COUNTER_LANE[0] = self.prev
+
+
 def _counters(owner, adjoint):
     """Arrival counters of one layer and direction for the in-launch split-K combine (locate_conv_counter_bytes: zero at
     creation, left zero by every launch).  Per layer, direction AND stream: the same layer may run on several streams at
@@ -1116,17 +1144,18 @@ def _counters(owner, adjoint):
     so the spare block is never shared by concurrent branches."""
     cache = owner.__dict__.setdefault("_locate_counters", {})
     sid = torch.cuda.current_stream().cuda_stream
-    key = (adjoint, sid)
+    lane = _COUNTER_LANE[0]
+    key = (adjoint, sid) if lane == 0 else (adjoint, "lane%d" % lane)
     buf = cache.get(key)
     if buf is not None and buf.device == owner.device:
         return buf
     if torch.cuda.is_current_stream_capturing():
-        buf = cache.get((adjoint, 0))
+        buf = cache.get((adjoint, 0)) if lane == 0 else None
         if buf is None or buf.device != owner.device:
             raise RuntimeError("hipGraph capture of a contraction that never ran eagerly: run one eager iteration first (its "
                                "arrival counters must exist before the capture)")
         return buf
-    for k in {key, (adjoint, 0)}:
+    for k in {key, (adjoint, 0), (adjoint, "lane1")}:
         if k not in cache or cache[k].device != owner.device:
             cache[k] = torch.zeros(lib().locate_conv_counter_bytes(), dtype=torch.uint8, device=owner.device)
     return cache[key]

@@ -126,6 +126,16 @@ class TrainStep:
             t_.record_stream(main)
         return generated, d_true, d_fake, d_aug
 
+    def begin_iteration(self, device):
+        """What both generator passes of an iteration (main.py:146 and :164: same latent, same weights) have in common, run
+        ahead of them so that they can execute CONCURRENTLY on two streams (graph.py): the iteration's zeroed block of
+        largest-magnitude words, and the generator's two power iterations in the reference's order - each pass then consumes
+        its queued (sigma, W v), exactly the sequence two forwards one after the other produce."""
+        from . import ops
+        ops.AMAX.new_step(device)
+        if getattr(self.gen, "batched_spectral_norm", False) and self.minibatches == 1:
+            self.gen.prefetch_spectral_norm(2)
+
     def d_generate(self, latent):
         """main.py:146: the D-step's generator pass (the reference builds a graph and drops it with .detach())."""
         from . import ops
