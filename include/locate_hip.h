@@ -161,8 +161,11 @@ int locate_conv_pack_panel(const int* geom, int adjoint, const float* w, float* 
 /* all panels of a network in one launch (after an optimizer step): one HOST record of locate_conv_pack_job_bytes()
  * per panel, filled by locate_conv_pack_job (block_start = running sum of *blocks_out), uploaded by the caller */
 size_t locate_conv_pack_job_bytes(void);
+/* direct != 0: RE-packing of a panel that has been packed in full before, in one pass (piece planes straight from the weights,
+ * fp32 rows only where a kernel reads them).  fp16-piece panels need weight_absmax for it: locate_absmax_words() device words
+ * with the largest magnitude of w as it is now (locate_nadam_step leaves them per tensor); else the two-pass form is taken */
 int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
-                         int* blocks_out);
+                         int* blocks_out, int direct, const void* weight_absmax);
 int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16 /* some job has the format bit */,
                             void* stream);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
@@ -297,7 +300,8 @@ int locate_multi_copy_chunk_elems(void);
 int locate_multi_copy(const void* tensors, const void* chunks, int n_chunks, int direction, float scale, void* stream);
 
 /* ---- fused multi-tensor Nadam (libs/nadam.py:31-89); per-tensor (step, m_schedule) state lives on device ---- */
-size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n} */
+size_t locate_nadam_tensor_record_bytes(void);   /* {float* p; const float* g; float* m; float* v; double* sched; int64 n;
+                                                     uint32* absmax (nullable: locate_absmax_words() words, receive max |p| after the step)} */
 int locate_nadam_chunk_elems(void);
 int locate_nadam_step(const void* tensors, void* coef, const void* chunks, int n_tensors, int n_chunks, double lr, double beta1,
                       double beta2, double eps, double schedule_decay, double weight_decay, void* stream);

@@ -76,7 +76,7 @@ PROTOTYPES = {
     "locate_conv_panel_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_pack_job_bytes": (c_sz, []),
-    "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip]),
+    "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip, c_i, c_p]),
     "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_counter_bytes": (c_sz, []),
@@ -126,7 +126,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 6
+EXPECTED_ABI = 7
 
 
 _lib = None

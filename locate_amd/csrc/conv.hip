@@ -78,6 +78,13 @@ struct PackArgs {
     int gHW, gW, dy0, dys, dx0, dxs;   // geometry of the gathered tensor and of the tap grid
     int dmin;                          // min over the taps of dy*gW + dx (<= 0)
     int fmt;                           // split section: 0 = three bf16 planes, 1 = header + two fp16 planes
+    // DIRECT re-packing (fmt 1 only): the weights' largest magnitude is already known (AMAX_WORDS words left by the optimizer
+    // kernel, nadam.hip), so the packing blocks write the two scaled fp16 planes themselves - no second pass over an fp32
+    // intermediate - and, where no kernel reads the K-major fp32 rows (every panel but single-tap ones: pointwise / 1x1-map
+    // kernels), do not write those either.  The offset tables and zero tails of an earlier full packing stay as they are.
+    const unsigned* wmax;              // fmt 1, direct form: the weights' absmax words
+    int direct;                        // 0: the two-pass form (fp32 rows, maximum folded in while packing, split pass)
+    int keep_f32;                      // direct form: also refresh the fp32 rows
 };
 
 // fmt 0: the split section holds the three bf16 planes; fmt 1 ("fp16 pieces", see conv_igemm_bx6_kernel NP = 2): a 4-dword
@@ -144,6 +151,27 @@ __device__ __forceinline__ void pack_publish_absmax(float m, const PackArgs* pha
 
 #define PACK_MAX_TAPS 32
 #define PACK_SMEM (256 * (PACK_MAX_TAPS + 1))      // floats; also holds the 64 x 65 transpose tile
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2_f16x8(const float (&v)[8], float sc, uint4& h, uint4& l);
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l);
+
+// direct form: one chunk of 8 consecutive k for one column -> the panel's planes (two scaled fp16 pieces, or three bf16 pieces)
+__device__ __forceinline__ void pack_emit_chunk(const PackArgs& a, const float (&v)[8], float sc, int64_t i) {
+    const int64_t plane = (int64_t)(a.rows / 8) * a.ld;
+    uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
+    if (a.fmt) {
+        uint4 h, l;
+        split2_f16x8(v, sc, h, l);
+        w3[i] = h;
+        w3[plane + i] = l;
+    } else {
+        bf16x8 h, m, l;
+        split3_bf16x8(v, h, m, l);
+        w3[i] = *reinterpret_cast<uint4*>(&h);
+        w3[plane + i] = *reinterpret_cast<uint4*>(&m);
+        w3[2 * plane + i] = *reinterpret_cast<uint4*>(&l);
+    }
+}
 
 // generic element-wise form (any tap count): virtual grid (nbx, nphase)
 __device__ __forceinline__ void pack_generic_body(const PackBatch& batch, int bx, int by, int nbx, float* smem) {
@@ -192,12 +220,81 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
         am = fmaxf(am, fabsf(v));
     }
     __syncthreads();
+    if (a.direct) {
+        // direct form: the tile's 8 k-blocks x 64 columns as piece chunks, two per thread; consecutive threads write
+        // consecutive 16-byte chunks of a plane row
+        const unsigned bits = a.fmt ? absmax_read(a.wmax) : 0u;
+        const float sc = pow2f(f16_scale_exp(bits));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kb = (threadIdx.x >> 6) + 4 * q, m = m0 + tx;
+            if (k0 + kb * 8 < a.rows && m < a.ld) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[tx][kb * 8 + e];
+                pack_emit_chunk(a, v, sc, (int64_t)(k0 / 8 + kb) * a.ld + m);
+            }
+        }
+        if (a.fmt && bx == 0 && by == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld)) = bits;
+        if (!a.keep_f32) return;
+    }
     for (int j = ty; j < 64; j += 4) {
         const int k = k0 + j, m = m0 + tx;
         if (k < a.rows && m < a.ld) a.out[(int64_t)k * a.ld + m] = tile[tx][j];
     }
+    if (a.direct) return;               // tables and header: from the panel's first (two-pass) packing / written above
     if (by == 0 && threadIdx.x < 64 && k0 + (int)threadIdx.x < a.rows) pack_tables(a, k0 + threadIdx.x);
     if (a.fmt) pack_publish_absmax(am, &a, 1, smem + 64 * 65);       // PACK_SMEM floats: room behind the tile
+}
+
+// Direct form of the adjoint packer (see PackArgs::wmax): a block stages eight weight rows m x 32 channels (all taps) in LDS
+// - eight contiguous reads - and writes, for every sub-pixel phase, the chunks of 8 consecutive k = (m, tap) it now holds for
+// its 32 columns: 8 T / 8 = T chunks per phase and column, 512-byte runs per plane row.  virtual grid (ld / 32, ceil(M / 8)).
+#define PACKD_MB 8
+#define PACKD_CS 32
+__device__ __forceinline__ void pack_adjoint_direct_body(const PackBatch& batch, int nphase, int bx, int by, float* lds) {
+    const PackArgs& a0 = batch.ph[0];
+    const int KK = a0.KH * a0.KW, S = KK | 1;
+    const int m0 = by * PACKD_MB, c0 = bx * PACKD_CS;
+    const int cn = min(PACKD_CS, a0.C - c0);
+    for (int mm = 0; mm < PACKD_MB; ++mm) {
+        const int m = m0 + mm;
+        if (m >= a0.M || cn <= 0) continue;
+        const float* src = a0.w + ((int64_t)m * a0.C + c0) * KK;
+        for (int idx = threadIdx.x; idx < cn * KK; idx += 256) {
+            const int cl = idx / KK, t = idx - cl * KK;
+            lds[(mm * PACKD_CS + cl) * S + t] = src[idx];
+        }
+    }
+    __syncthreads();
+    const unsigned bits = a0.fmt ? absmax_read(a0.wmax) : 0u;
+    const float sc = pow2f(f16_scale_exp(bits));
+    const int cl = threadIdx.x & (PACKD_CS - 1), sub = threadIdx.x >> 5;          // column, chunk lane (0 .. 7)
+    const int col = c0 + cl;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const PackArgs& a = batch.ph[ph];
+        const int T = a.TH * a.TW;
+        if (T <= 0) continue;
+        // rows k = m T + r of this block: m0 T ... (m0 + 8) T - 1 = T whole chunks starting at chunk m0 T / 8
+        for (int ch = sub; ch < T; ch += 8) {
+            if (col >= a.ld || (by * T + ch) * 8 >= a.rows) continue;          // (the last row group may reach past the zero tail)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kl = ch * 8 + e;                     // local row 0 .. 8 T - 1
+                const int mm = kl / T, r = kl - mm * T;
+                const int th = r / a.TW, tw = r - th * a.TW;
+                const int t = (a.kh0 + a.s * th) * a.KW + a.kw0 + a.s * tw;
+                v[e] = (m0 + mm < a.M && cl < cn) ? lds[(mm * PACKD_CS + cl) * S + t] : 0.0f;
+            }
+            pack_emit_chunk(a, v, sc, (int64_t)(by * T + ch) * a.ld + col);
+            if (a.keep_f32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a.out[(int64_t)((by * T + ch) * 8 + e) * a.ld + col] = v[e];
+            }
+        }
+        if (a.fmt && bx == 0 && by == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld)) = bits;
+    }
 }
 
 // mode 1 (data adjoint, all sub-pixel phases at once): for one m, W[m] is a [C][KH*KW] matrix; a block stages 256
@@ -314,6 +411,7 @@ __device__ __forceinline__ void split2_f16_pair(float v0, float v1, unsigned& h,
 // second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k), or
 // its two scaled fp16 planes
 __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int nbx) {
+    if (a.direct) return;              // direct form: the packing blocks wrote the planes
     const float* w = a.out;
     uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
     const int64_t total = (int64_t)(a.rows / 8) * a.ld;
@@ -348,7 +446,7 @@ __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int n
 // One packing job = all phases of one panel; `kind` selects the body, (gx, gy) is its virtual grid.
 struct PackJob {
     PackBatch batch;
-    int nphase, kind;          // kind 0: transpose, 1: adjoint, 2: generic
+    int nphase, kind;          // kind 0: transpose, 1: adjoint, 2: generic, 3: adjoint, direct form
     int gx, gy;
     int block_start, pad;      // first block of this job inside a batched launch
 };
@@ -359,6 +457,8 @@ static PackJob make_pack_job(const PackBatch& b, int nphase) {
     const PackArgs& a0 = b.ph[0];
     if (a0.mode == 0 && nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW) {
         j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
+    } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS && a0.direct) {
+        j.kind = 3; j.gx = (a0.ld + PACKD_CS - 1) / PACKD_CS; j.gy = (a0.M + PACKD_MB - 1) / PACKD_MB;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS) {
         j.kind = 1; j.gx = (a0.ld + 255) / 256; j.gy = a0.M + 1;
     } else {
@@ -376,6 +476,7 @@ __device__ __forceinline__ void pack_job_body(const PackJob& j, int local, float
     const int bx = local % j.gx, by = local / j.gx;
     if (j.kind == 0) pack_transpose_body(j.batch.ph[0], bx, by, smem);
     else if (j.kind == 1) pack_adjoint_body(j.batch, j.nphase, bx, by, smem);
+    else if (j.kind == 3) pack_adjoint_direct_body(j.batch, j.nphase, bx, by, smem);
     else pack_generic_body(j.batch, bx, by, j.gx, smem);
 }
 
@@ -391,7 +492,7 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const PackJob job) {
 
 // fp16-piece panels only: zero the absmax words (one thread per (job, phase)), then take the maxima
 __device__ __forceinline__ void pack_clear_one(const PackJob& j, int ph) {
-    if (ph < j.nphase && j.batch.ph[ph].fmt) {
+    if (ph < j.nphase && j.batch.ph[ph].fmt && !j.batch.ph[ph].direct) {
         const PackArgs& a = j.batch.ph[ph];
         unsigned* hdr = reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld));
         hdr[0] = 0u; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u;
@@ -1599,7 +1700,7 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
         pa.K = g.C * pa.TH * pa.TW; pa.rows = round_up(pa.K, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.M, 32);
         pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = pa.kh0 - g.pad_h; pa.dys = 1; pa.dx0 = pa.kw0 - g.pad_w; pa.dxs = 1;
         pa.dmin = tap_dmin(pa);
-        pa.fmt = fmt;
+        pa.fmt = fmt; pa.wmax = nullptr; pa.direct = 0; pa.keep_f32 = 1;
         batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
@@ -1633,7 +1734,7 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
                 pa.K = g.M * TH * TW; pa.rows = round_up(pa.K > 0 ? pa.K : 1, IG_KPAD) + IG_TAIL; pa.ld = round_up(g.C, 32);
                 pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
                 pa.dmin = tap_dmin(pa);
-                pa.fmt = fmt;
+                pa.fmt = fmt; pa.wmax = nullptr; pa.direct = 0; pa.keep_f32 = 1;
                 batch.ph[p.nphase - 1] = pa;
                 phase_finish(ph, pa, pa.out);
                 ph.T = TH * TW;
@@ -1675,8 +1776,13 @@ LOCATE_API int locate_conv_pack_panel(const int* geom, int adjoint, const float*
 // calls locate_conv_pack_panels.  Records hold raw pointers: rebuild them when a weight or panel buffer moves.
 LOCATE_API size_t locate_conv_pack_job_bytes(void) { return sizeof(PackJob); }
 
+// direct != 0: the job RE-packs a panel that has been packed in full before (its offset tables and zero tails are kept) in its
+// direct form - the piece planes in one pass, straight from the weights, the K-major fp32 rows only where a kernel reads them.
+// A fp16-piece panel needs weight_absmax for that: locate_absmax_words() device words holding the largest magnitude of w as it
+// is NOW (the optimizer kernel leaves them, locate_nadam_step); without them - and for geometries the direct bodies do not
+// cover - the job silently takes the two-pass form.
 LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
-                                    int* blocks_out) {
+                                    int* blocks_out, int direct, const void* weight_absmax) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_pack_job")) return e;
     LOCATE_REQUIRE(w && panel && job_out && blocks_out && block_start >= 0, "locate_conv_pack_job: bad arguments");
@@ -1684,6 +1790,22 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
     PackBatch batch;
     if (int e = conv_plan(g, adjoint, w, panel, p, nullptr, nullptr, false, nullptr, &batch)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "locate_conv_pack_job: empty panel");
+    if (direct && (weight_absmax || !(adjoint & 2))) {
+        const PackArgs& a0 = batch.ph[0];
+        const bool transpose = a0.mode == 0 && p.nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW;
+        const bool adj = a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS;
+        if (transpose || adj) {
+            // single-tap panels feed the pointwise / 1x1-map kernels, which read the fp32 rows; the debug library's fp32-MFMA
+            // fallback reads them for every panel
+            bool keep = path_disabled("bx6") || path_disabled("direct_planes_only");
+            for (int i = 0; i < p.nphase; ++i) keep = keep || (p.nphase == 1 && batch.ph[i].TH * batch.ph[i].TW == 1);
+            for (int i = 0; i < p.nphase; ++i) {
+                batch.ph[i].wmax = static_cast<const unsigned*>(weight_absmax);
+                batch.ph[i].direct = 1;
+                batch.ph[i].keep_f32 = keep ? 1 : 0;
+            }
+        }
+    }
     PackJob j = make_pack_job(batch, p.nphase);
     j.block_start = block_start;
     memcpy(job_out, &j, sizeof(PackJob));

@@ -19,6 +19,9 @@ struct NadamTensor {
     float* v;
     double* sched;     // [2]: step count, m_schedule
     long long n;
+    unsigned* absmax;  // nullable: AMAX_WORDS words that receive the largest magnitude of the UPDATED tensor (bit pattern,
+                       // spread like every other absmax slot, common.h) - what the fp16-piece weight panels are scaled by;
+                       // re-packing them then needs no pass of its own over the weights (conv.hip, direct packing)
 };
 
 struct NadamCoef {
@@ -40,6 +43,8 @@ __global__ void __launch_bounds__(64) nadam_schedule_kernel(const NadamTensor* _
     const double ms_next = ms_new * mc_t1;
     st[0] = t;
     st[1] = ms_new;
+    if (tensors[i].absmax)
+        for (int k = 0; k < AMAX_LINES; ++k) tensors[i].absmax[k * AMAX_STRIDE] = 0u;      // the update kernel folds the new maximum in
     NadamCoef c;
     c.c_grad = (float)(-lr * (1.0 - mc_t) / (1.0 - ms_new));
     c.c_mom = (float)(-lr * mc_t1 / (1.0 - ms_next));
@@ -58,6 +63,8 @@ __global__ void __launch_bounds__(256) nadam_update_kernel(const NadamTensor* __
     long long end = begin + NADAM_CHUNK;
     if (end > T.n) end = T.n;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    __shared__ float scratch[16];
+    float amax = 0.0f;
     for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
         float p = T.p[i];
         const float g = wd != 0.0f ? fmaf(wd, p, T.g[i]) : T.g[i];          // nadam.py:65-66: grad + weight_decay * p
@@ -71,13 +78,15 @@ __global__ void __launch_bounds__(256) nadam_update_kernel(const NadamTensor* __
         T.m[i] = m;
         T.v[i] = v;
         T.p[i] = p;
+        amax = fmaxf(amax, fabsf(p));
     }
+    if (T.absmax) absmax_publish(amax, scratch, T.absmax);          // wave-uniform condition: every thread of the block takes it
 }
 
 LOCATE_API size_t locate_nadam_tensor_record_bytes(void) { return sizeof(NadamTensor); }
 LOCATE_API int locate_nadam_chunk_elems(void) { return NADAM_CHUNK; }
 
-// tensors: DEVICE array of n_tensors records {p, g, m, v, sched, n}; coef: DEVICE scratch of n_tensors * 16 bytes;
+// tensors: DEVICE array of n_tensors records {p, g, m, v, sched, n, absmax (nullable)}; coef: DEVICE scratch of n_tensors * 16 bytes;
 // chunks: DEVICE array of n_chunks (tensor index, chunk index) int pairs covering every tensor in
 // locate_nadam_chunk_elems() pieces.
 LOCATE_API int locate_nadam_step(const void* tensors, void* coef, const void* chunks, int n_tensors, int n_chunks, double lr,

@@ -1043,6 +1043,9 @@ def _panel(owner, w, geom, garr, adjoint):
 #   (instead of three launches per layer and graph).  The result is written to a persistent buffer that becomes
 #   v.grad (accumulated into an existing foreign .grad).
 # ------------------------------------------------------------------------------------------------
+DIRECT_REPACK = os.environ.get("LOCATE_DIRECT_REPACK", "1") != "0"
+
+
 class _PackPlans:
     cache = {}       # signature of the stale set -> (device job table, n_jobs, total_blocks)
 
@@ -1064,7 +1067,16 @@ def refresh_panels(params):
                 stale.append((w, key, buf, geom))
     if not stale:
         return
-    sig = tuple((key[2], key[0], buf.data_ptr()) + tuple(geom) for _, key, buf, geom in stale)
+    # the optimizer kernel leaves the updated weights' largest magnitude per tensor (optim.Nadam._absmax_words, stamped with the
+    # parameter version it belongs to): fp16-piece panels are then re-packed in one pass (conv.hip, direct form).  Anything else -
+    # weights changed by other means, bf16-piece panels - takes the two-pass form.
+    def wmax_of(w):
+        hold = w.__dict__.get("_locate_wmax") if DIRECT_REPACK else None
+        return hold[0].data_ptr() if (hold is not None and hold[1] == w._version and hold[0].device == w.device) else None
+
+    wm = [wmax_of(w) if key[0] & 2 else None for w, key, _, _ in stale]
+    direct = int(DIRECT_REPACK)          # bf16-piece panels need no scale: always one pass
+    sig = tuple((key[2], key[0], buf.data_ptr(), m, direct) + tuple(geom) for (_, key, buf, geom), m in zip(stale, wm))
     plan = _PackPlans.cache.get(sig)
     if plan is None:
         rec = L.locate_conv_pack_job_bytes()
@@ -1073,7 +1085,7 @@ def refresh_panels(params):
         for i, (w, key, buf, geom) in enumerate(stale):
             nb = ctypes.c_int(0)
             check(L.locate_conv_pack_job(_geom(geom), key[0], key[2], _p(buf), start, ctypes.addressof(host) + i * rec,
-                                         ctypes.byref(nb)), "locate_conv_pack_job")
+                                         ctypes.byref(nb), direct, wm[i]), "locate_conv_pack_job")
             start += nb.value
         table = torch.frombuffer(host, dtype=torch.uint8).clone().to(stale[0][0].device)
         plan = (table, len(stale), start)

@@ -58,22 +58,32 @@ class Nadam(torch.optim.Optimizer):
                 if k in st and not st[k].is_contiguous():
                     st[k] = st[k].contiguous()
 
+    def _absmax_words(self, p):
+        """Device words that receive the largest magnitude of p after every step (the fp16-piece weight panels' scale: their
+        re-packing then needs no pass of its own over the weights, ops.refresh_panels).  Only weights of 2 or more dimensions
+        can own panels; the words are valid for the parameter version stamped in step()."""
+        hold = p.__dict__.get("_locate_wmax")
+        if hold is None or hold[0].device != p.device:
+            hold = [torch.zeros(lib().locate_absmax_words(), dtype=torch.int32, device=p.device), -1]
+            p.__dict__["_locate_wmax"] = hold
+        return hold[0]
+
     def _table(self, plist):
         """Device tables for one set of (parameter, gradient, state) buffers; cached on ALL the addresses a record holds."""
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(self._state_for(p)[k].data_ptr() for k in ("exp_avg", "exp_avg_sq", "sched"))
-                    for p in plist)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self._absmax_words(p).data_ptr())
+                    + tuple(self._state_for(p)[k].data_ptr() for k in ("exp_avg", "exp_avg_sq", "sched")) for p in plist)
         tab = self._tables.get(key)
         if tab is not None:
             return tab
         L = lib()
-        assert L.locate_nadam_tensor_record_bytes() == 48
+        assert L.locate_nadam_tensor_record_bytes() == 56
         chunk = L.locate_nadam_chunk_elems()
         rec = bytearray()
         chunks = []
         for i, p in enumerate(plist):
             st = self._state_for(p)
-            rec += struct.pack("<5Qq", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                               st["sched"].data_ptr(), p.numel())
+            rec += struct.pack("<5QqQ", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                               st["sched"].data_ptr(), p.numel(), self._absmax_words(p).data_ptr())
             chunks.extend((i, c) for c in range((p.numel() + chunk - 1) // chunk))
         dev = plist[0].device
         # pinned staging + async copies: legal inside a hipGraph capture (the memcpy nodes re-read these host
@@ -112,4 +122,6 @@ class Nadam(torch.optim.Optimizer):
                                           torch.cuda.current_stream().cuda_stream), "locate_nadam_step")
             # the kernel writes through raw pointers: tell autograd / the packed-panel cache that the weights changed
             torch._C._increment_version(plist)
+            for p in plist:
+                p.__dict__["_locate_wmax"][1] = p._version        # the words hold the maximum of THIS version of the weights
         return loss

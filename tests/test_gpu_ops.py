@@ -1122,3 +1122,63 @@ def test_weight_side_group_dots(kind, k, s, p, cin, cout, H, Bg, groups):
         got = float(part[kk * npg:(kk + 1) * npg].sum())
         assert abs(got - dot_ref) <= 2e-5 * float((gd[sl] * y.detach()).abs().sum()), (kk, got, dot_ref)
     assert_close(gw.cpu().double(), gw_ref, 2e-5, "gw")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,B,H", [("conv", 48, 40, 3, 1, 1, 2, 8), ("convT", 40, 72, 4, 2, 1, 2, 4), ("conv", 20, 33, 5, 2, 2, 2, 8),
+                                                       ("convT", 3, 5, 4, 2, 1, 2, 4), ("conv", 64, 64, 1, 1, 0, 2, 4), ("conv", 12, 9, 5, 1, 2, 2, 6),
+                                                       ("conv", 8, 1, 3, 1, 1, 3, 1)])
+@pytest.mark.parametrize("fmt", [2, 0])
+def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fmt):
+    """A fp16-piece panel re-packed in its direct form (weights' largest magnitude given: the two planes in one pass, fp32 rows
+    only for single-tap panels) serves forward and input gradient exactly like a freshly two-pass-packed panel of the same
+    weights - for both directions, full-tap, sub-pixel-phase and single-tap panels, row counts that are no multiple of 8."""
+    import ctypes
+    from locate_amd import ops
+    from locate_amd._lib import check, lib
+    L = lib()
+    torch.manual_seed(cin * 7 + cout)
+    S = lambda: torch.cuda.current_stream().cuda_stream
+    spec = ops.ConvSpec(kind, k, k, s, p, p)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w_old = torch.randn(wshape, device=dev())
+    w_new = (w_old * 1.7 + 0.3 * torch.randn(wshape, device=dev())).contiguous()
+    x = torch.randn(B, cin, H, H, device=dev())
+    geom, out_shape = spec.geometry(tuple(x.shape), wshape)
+    garr = (ctypes.c_int * 12)(*geom)
+    gy = torch.randn(out_shape, device=dev())
+    nw = L.locate_absmax_words()
+    amax = torch.zeros(3 * nw, dtype=torch.int32, device=dev())
+    check(L.locate_absmax(x.data_ptr(), x.numel(), amax[0:].data_ptr(), S()))
+    check(L.locate_absmax(gy.data_ptr(), gy.numel(), amax[nw:].data_ptr(), S()))
+    check(L.locate_absmax(w_new.data_ptr(), w_new.numel(), amax[2 * nw:].data_ptr(), S()))
+    one = torch.ones(1, device=dev())
+    res = {}
+    for adjoint in (0, 1):
+        nbytes = max(L.locate_conv_panel_bytes(garr, adjoint | fmt), 16)
+        fresh = torch.zeros(nbytes, dtype=torch.uint8, device=dev())
+        check(L.locate_conv_pack_panel(garr, adjoint | fmt, w_new.data_ptr(), fresh.data_ptr(), S()))
+        reused = torch.zeros(nbytes, dtype=torch.uint8, device=dev())
+        check(L.locate_conv_pack_panel(garr, adjoint | fmt, w_old.data_ptr(), reused.data_ptr(), S()))          # its first, full packing
+        job = ctypes.create_string_buffer(L.locate_conv_pack_job_bytes())
+        nb = ctypes.c_int(0)
+        check(L.locate_conv_pack_job(garr, adjoint | fmt, w_new.data_ptr(), reused.data_ptr(), 0, job, ctypes.byref(nb), 1, amax[2 * nw:].data_ptr() if fmt else None))
+        table = torch.frombuffer(job, dtype=torch.uint8).clone().to(dev())
+        check(L.locate_conv_pack_panels(table.data_ptr(), 1, nb.value, int(fmt != 0), S()))
+        res[adjoint] = (fresh, reused)
+    ws = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev())
+    outs = []
+    for which in (0, 1):
+        inp, out, pan, ax = (x, torch.empty(out_shape, device=dev()), res[0][which], amax[0:]) if kind == "conv" else \
+                            (gy, torch.empty_like(x), res[0][which], amax[nw:])
+        check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(), out.stride(0),
+                                ws.data_ptr(), None, 2 if fmt else 0, ax.data_ptr() if fmt else None, None, S()), "locate_conv_fwd")
+        inp2, out2, pan2, ax2 = (gy, torch.empty_like(x), res[1][which], amax[nw:]) if kind == "conv" else \
+                                (x, torch.empty(out_shape, device=dev()), res[1][which], amax[0:])
+        check(L.locate_conv_dgrad(garr, inp2.data_ptr(), inp2.stride(0), pan2.data_ptr(), one.data_ptr(), 0, 0, None, out2.data_ptr(),
+                                  out2.stride(0), ws.data_ptr(), None, 2 if fmt else 0, ax2.data_ptr() if fmt else None, S()), "locate_conv_dgrad")
+        outs.append((out, out2))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all() and a.abs().max() > 0
+        assert_close(b.cpu(), a.cpu(), 1e-6, "direct vs two-pass")

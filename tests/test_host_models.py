@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     from locate_amd._lib import EXPECTED_ABI
     assert handle.locate_abi_version() == EXPECTED_ABI
     assert handle.locate_sn_table_record_bytes() == 80
-    assert handle.locate_nadam_tensor_record_bytes() == 48
+    assert handle.locate_nadam_tensor_record_bytes() == 56
 
 
 def test_no_cpu_fallback():
