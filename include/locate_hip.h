@@ -166,8 +166,10 @@ size_t locate_conv_pack_job_bytes(void);
  * with the largest magnitude of w as it is now (locate_nadam_step leaves them per tensor); else the two-pass form is taken */
 int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
                          int* blocks_out, int direct, const void* weight_absmax);
-int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16 /* some job has the format bit */,
-                            void* stream);
+/* any_f16: some job is a two-pass fp16-piece panel; any_two_pass: some job is in the two-pass form at all (both 0 when every
+ * job took the direct form, locate_conv_pack_job_is_direct: then the whole re-packing is one launch) */
+int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int any_two_pass, void* stream);
+int locate_conv_pack_job_is_direct(const void* job);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
 /* arrival counters for split-K launches that combine their partial tiles INSIDE the launch (the tile's last-arriving block
  * sums them in a fixed order: bit-reproducible): locate_conv_counter_bytes() bytes of device memory, zero before their first

@@ -77,7 +77,8 @@ PROTOTYPES = {
     "locate_conv_pack_panel": (c_i, [c_ip, c_i, c_p, c_p, c_p]),
     "locate_conv_pack_job_bytes": (c_sz, []),
     "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip, c_i, c_p]),
-    "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_i, c_p]),
+    "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p]),
+    "locate_conv_pack_job_is_direct": (c_i, [c_p]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_counter_bytes": (c_sz, []),
     "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p, c_p]),

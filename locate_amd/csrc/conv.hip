@@ -251,50 +251,60 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
 // - eight contiguous reads - and writes, for every sub-pixel phase, the chunks of 8 consecutive k = (m, tap) it now holds for
 // its 32 columns: 8 T / 8 = T chunks per phase and column, 512-byte runs per plane row.  virtual grid (ld / 32, ceil(M / 8)).
 #define PACKD_MB 8
-#define PACKD_CS 32
+static_assert(13312 >= PACK_SMEM, "direct packing reuses the packers' LDS block");
+#define PACKD_SMEM 13312          // floats: 8 rows x 64 channels x up to 25 (+1) taps, or x 32 channels for up to 32 taps
+static inline __host__ __device__ int packd_cs(int KK) { return PACKD_MB * 64 * (KK | 1) <= PACKD_SMEM ? 64 : 32; }
 __device__ __forceinline__ void pack_adjoint_direct_body(const PackBatch& batch, int nphase, int bx, int by, float* lds) {
     const PackArgs& a0 = batch.ph[0];
     const int KK = a0.KH * a0.KW, S = KK | 1;
-    const int m0 = by * PACKD_MB, c0 = bx * PACKD_CS;
-    const int cn = min(PACKD_CS, a0.C - c0);
-    for (int mm = 0; mm < PACKD_MB; ++mm) {
-        const int m = m0 + mm;
-        if (m >= a0.M || cn <= 0) continue;
-        const float* src = a0.w + ((int64_t)m * a0.C + c0) * KK;
-        for (int idx = threadIdx.x; idx < cn * KK; idx += 256) {
-            const int cl = idx / KK, t = idx - cl * KK;
-            lds[(mm * PACKD_CS + cl) * S + t] = src[idx];
+    const int CS = packd_cs(KK);
+    const int m0 = by * PACKD_MB, c0 = bx * CS;
+    const int cn = min(CS, a0.C - c0);
+    const DivU32 dk((unsigned)KK);
+    if (cn > 0) {
+        const int run = cn * KK;
+#pragma unroll
+        for (int mm = 0; mm < PACKD_MB; ++mm) {
+            if (m0 + mm >= a0.M) break;
+            const float* src = a0.w + ((int64_t)(m0 + mm) * a0.C + c0) * KK;
+            for (int idx = threadIdx.x; idx < run; idx += 256) {
+                unsigned cl, t;
+                dk.divmod((unsigned)idx, cl, t);
+                lds[(mm * CS + (int)cl) * S + (int)t] = src[idx];
+            }
         }
     }
     __syncthreads();
     const unsigned bits = a0.fmt ? absmax_read(a0.wmax) : 0u;
     const float sc = pow2f(f16_scale_exp(bits));
-    const int cl = threadIdx.x & (PACKD_CS - 1), sub = threadIdx.x >> 5;          // column, chunk lane (0 .. 7)
-    const int col = c0 + cl;
-    for (int ph = 0; ph < nphase; ++ph) {
+    // work items (phase, chunk, column), columns fastest: T chunks of 8 rows k = (m, tap) per phase for this block's 8 m
+    int tsum = 0;
+    for (int ph = 0; ph < nphase; ++ph) tsum += batch.ph[ph].TH * batch.ph[ph].TW;
+    const int csh = CS == 64 ? 6 : 5;
+    for (int it = threadIdx.x; it < (tsum << csh); it += 256) {
+        const int cl = it & (CS - 1);
+        int ch = it >> csh, ph = 0;
+        while (ch >= batch.ph[ph].TH * batch.ph[ph].TW) { ch -= batch.ph[ph].TH * batch.ph[ph].TW; ++ph; }
         const PackArgs& a = batch.ph[ph];
-        const int T = a.TH * a.TW;
-        if (T <= 0) continue;
-        // rows k = m T + r of this block: m0 T ... (m0 + 8) T - 1 = T whole chunks starting at chunk m0 T / 8
-        for (int ch = sub; ch < T; ch += 8) {
-            if (col >= a.ld || (by * T + ch) * 8 >= a.rows) continue;          // (the last row group may reach past the zero tail)
-            float v[8];
+        const int T = a.TH * a.TW, col = c0 + cl;
+        if (col >= a.ld || (by * T + ch) * 8 >= a.rows) continue;          // (the last row group may reach past the zero tail)
+        int mm = (ch * 8) / T, r = ch * 8 - mm * T;
+        int th = r / a.TW, tw = r - th * a.TW;
+        float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kl = ch * 8 + e;                     // local row 0 .. 8 T - 1
-                const int mm = kl / T, r = kl - mm * T;
-                const int th = r / a.TW, tw = r - th * a.TW;
-                const int t = (a.kh0 + a.s * th) * a.KW + a.kw0 + a.s * tw;
-                v[e] = (m0 + mm < a.M && cl < cn) ? lds[(mm * PACKD_CS + cl) * S + t] : 0.0f;
-            }
-            pack_emit_chunk(a, v, sc, (int64_t)(by * T + ch) * a.ld + col);
-            if (a.keep_f32) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a.out[(int64_t)((by * T + ch) * 8 + e) * a.ld + col] = v[e];
-            }
+        for (int e = 0; e < 8; ++e) {
+            const int t = (a.kh0 + a.s * th) * a.KW + a.kw0 + a.s * tw;
+            v[e] = (m0 + mm < a.M && cl < cn) ? lds[(mm * CS + cl) * S + t] : 0.0f;
+            if (++tw == a.TW) { tw = 0; if (++th == a.TH) { th = 0; ++mm; } }
         }
-        if (a.fmt && bx == 0 && by == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld)) = bits;
+        pack_emit_chunk(a, v, sc, (int64_t)(by * T + ch) * a.ld + col);
+        if (a.keep_f32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a.out[(int64_t)((by * T + ch) * 8 + e) * a.ld + col] = v[e];
+        }
     }
+    if (a0.fmt && bx == 0 && by == 0 && threadIdx.x < nphase)
+        *reinterpret_cast<unsigned*>(batch.ph[threadIdx.x].out + panel_split_offset_dev(batch.ph[threadIdx.x].rows, batch.ph[threadIdx.x].ld)) = bits;
 }
 
 // mode 1 (data adjoint, all sub-pixel phases at once): for one m, W[m] is a [C][KH*KW] matrix; a block stages 256
@@ -458,7 +468,7 @@ static PackJob make_pack_job(const PackBatch& b, int nphase) {
     if (a0.mode == 0 && nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW) {
         j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS && a0.direct) {
-        j.kind = 3; j.gx = (a0.ld + PACKD_CS - 1) / PACKD_CS; j.gy = (a0.M + PACKD_MB - 1) / PACKD_MB;
+        j.kind = 3; j.gx = (a0.ld + packd_cs(a0.KH * a0.KW) - 1) / packd_cs(a0.KH * a0.KW); j.gy = (a0.M + PACKD_MB - 1) / PACKD_MB;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS) {
         j.kind = 1; j.gx = (a0.ld + 255) / 256; j.gy = a0.M + 1;
     } else {
@@ -481,7 +491,7 @@ __device__ __forceinline__ void pack_job_body(const PackJob& j, int local, float
 }
 
 __global__ void __launch_bounds__(256) pack_job_kernel(const PackJob job) {
-    __shared__ float smem[PACK_SMEM];
+    __shared__ float smem[PACKD_SMEM];
     pack_job_body(job, blockIdx.x, smem);
 }
 
@@ -511,7 +521,7 @@ __global__ void __launch_bounds__(256) pack_split_jobs_kernel(const PackJob* __r
 
 // many panels in one launch: `jobs` (device) sorted by block_start; a block finds its job by bisection
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float smem[PACK_SMEM];
+    __shared__ float smem[PACKD_SMEM];
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1813,15 +1823,26 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
     return LOCATE_OK;
 }
 
-LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, void* stream) {
+// any_f16: some job is a TWO-PASS fp16-piece panel (its absmax header is cleared first); any_two_pass: some job is in the
+// two-pass form at all (the split launch is needed) - both 0 when every job was built in the direct form: one launch.
+LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int any_two_pass, void* stream) {
     LOCATE_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "locate_conv_pack_panels: bad arguments");
     if (any_f16)        // fp16-piece panels: zero the absmax words the packing blocks fold their maxima into
         pack_clear_jobs_kernel<<<(4 * n_jobs + 63) / 64, 64, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     pack_jobs_kernel<<<total_blocks, 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     LOCATE_LAUNCH_CHECK("locate_conv_pack_panels");
-    pack_split_jobs_kernel<<<dim3(PACK_SPLIT_BLOCKS, n_jobs, 4), 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs));
-    LOCATE_LAUNCH_CHECK("locate_conv_pack_panels(split)");
+    if (any_two_pass) {
+        pack_split_jobs_kernel<<<dim3(PACK_SPLIT_BLOCKS, n_jobs, 4), 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs));
+        LOCATE_LAUNCH_CHECK("locate_conv_pack_panels(split)");
+    }
     return LOCATE_OK;
+}
+// whether a job built by locate_conv_pack_job took the direct form (then it needs neither the clearing nor the split launch)
+LOCATE_API int locate_conv_pack_job_is_direct(const void* job) {
+    if (!job) return 0;
+    PackJob j;
+    memcpy(&j, job, sizeof(j));
+    return j.batch.ph[0].direct;
 }
 
 // optional activated second output of locate_conv_fwd (HOST struct, see IgParams::act_out)

@@ -1082,18 +1082,21 @@ def refresh_panels(params):
         rec = L.locate_conv_pack_job_bytes()
         host = ctypes.create_string_buffer(rec * len(stale))
         start = 0
+        two_pass = two_pass_f16 = 0
         for i, (w, key, buf, geom) in enumerate(stale):
             nb = ctypes.c_int(0)
             check(L.locate_conv_pack_job(_geom(geom), key[0], key[2], _p(buf), start, ctypes.addressof(host) + i * rec,
                                          ctypes.byref(nb), direct, wm[i]), "locate_conv_pack_job")
             start += nb.value
+            if not L.locate_conv_pack_job_is_direct(ctypes.addressof(host) + i * rec):
+                two_pass = 1
+                two_pass_f16 |= int(bool(key[0] & 2))
         table = torch.frombuffer(host, dtype=torch.uint8).clone().to(stale[0][0].device)
-        plan = (table, len(stale), start)
+        plan = (table, len(stale), start, two_pass_f16, two_pass)
         if len(_PackPlans.cache) > 16:
             _PackPlans.cache.clear()
         _PackPlans.cache[sig] = plan
-    check(L.locate_conv_pack_panels(_p(plan[0]), plan[1], plan[2], int(any(key[0] & 2 for _, key, _, _ in stale)), _stream()),
-          "locate_conv_pack_panels")
+    check(L.locate_conv_pack_panels(_p(plan[0]), plan[1], plan[2], plan[3], plan[4], _stream()), "locate_conv_pack_panels")
     for w, key, buf, geom in stale:
         w.__dict__["_locate_panels"][key] = (w._version, buf, geom)
 

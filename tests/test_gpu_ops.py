@@ -1154,6 +1154,7 @@ def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fm
     check(L.locate_absmax(w_new.data_ptr(), w_new.numel(), amax[2 * nw:].data_ptr(), S()))
     one = torch.ones(1, device=dev())
     res = {}
+    seen_direct = []
     for adjoint in (0, 1):
         nbytes = max(L.locate_conv_panel_bytes(garr, adjoint | fmt), 16)
         fresh = torch.zeros(nbytes, dtype=torch.uint8, device=dev())
@@ -1164,7 +1165,9 @@ def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fm
         nb = ctypes.c_int(0)
         check(L.locate_conv_pack_job(garr, adjoint | fmt, w_new.data_ptr(), reused.data_ptr(), 0, job, ctypes.byref(nb), 1, amax[2 * nw:].data_ptr() if fmt else None))
         table = torch.frombuffer(job, dtype=torch.uint8).clone().to(dev())
-        check(L.locate_conv_pack_panels(table.data_ptr(), 1, nb.value, int(fmt != 0), S()))
+        is_direct = L.locate_conv_pack_job_is_direct(job)          # 0: a geometry the direct bodies do not cover (tap sub-rectangle)
+        seen_direct.append(is_direct)
+        check(L.locate_conv_pack_panels(table.data_ptr(), 1, nb.value, 0 if is_direct else int(fmt != 0), 0 if is_direct else 1, S()))
         res[adjoint] = (fresh, reused)
     ws = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev())
     outs = []
@@ -1179,6 +1182,7 @@ def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fm
                                   out2.stride(0), ws.data_ptr(), None, 2 if fmt else 0, ax2.data_ptr() if fmt else None, S()), "locate_conv_dgrad")
         outs.append((out, out2))
     torch.cuda.synchronize()
+    assert any(seen_direct)
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(a).all() and a.abs().max() > 0
         assert_close(b.cpu(), a.cpu(), 1e-6, "direct vs two-pass")

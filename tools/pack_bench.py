@@ -40,7 +40,7 @@ def main():
                 nb = ctypes.c_int(0)
                 check(L.locate_conv_pack_job(garr, adjoint | 2, w.data_ptr(), buf.data_ptr(), 0, job, ctypes.byref(nb), int(wm is not None), wm))
                 table = torch.frombuffer(job, dtype=torch.uint8).clone().to(dev)
-                fn = lambda: check(L.locate_conv_pack_panels(table.data_ptr(), 1, nb.value, 1, S()))
+                fn = lambda: check(L.locate_conv_pack_panels(table.data_ptr(), 1, nb.value, int(wm is None), int(wm is None), S()))
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize()
