@@ -251,8 +251,9 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
 // - eight contiguous reads - and writes, for every sub-pixel phase, the chunks of 8 consecutive k = (m, tap) it now holds for
 // its 32 columns: 8 T / 8 = T chunks per phase and column, 512-byte runs per plane row.  virtual grid (ld / 32, ceil(M / 8)).
 #define PACKD_MB 8
-static_assert(13312 >= PACK_SMEM, "direct packing reuses the packers' LDS block");
-#define PACKD_SMEM 13312          // floats: 8 rows x 64 channels x up to 25 (+1) taps, or x 32 channels for up to 32 taps
+static_assert(8704 >= PACK_SMEM, "direct packing reuses the packers' LDS block");
+#define PACKD_SMEM 8704           // floats: 8 rows x 64 channels x up to 16 (+1) taps, or x 32 channels for up to 32 taps (34 KB:
+                                  // four blocks per CU - the packers are bandwidth kernels, a larger block cost them occupancy)
 static inline __host__ __device__ int packd_cs(int KK) { return PACKD_MB * 64 * (KK | 1) <= PACKD_SMEM ? 64 : 32; }
 __device__ __forceinline__ void pack_adjoint_direct_body(const PackBatch& batch, int nphase, int bx, int by, float* lds) {
     const PackArgs& a0 = batch.ph[0];
