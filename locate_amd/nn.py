@@ -164,6 +164,7 @@ class SpectralNorm(_Bound):
         """out (Conv2d / ConvTranspose2d only): a channel slice of a concatenation buffer to write the result into."""
         m = self.module
         x4, w4, spec, restore = self._plan(x)
+        ops.carry_amax(x, x4)          # a reshaped view has its source's largest magnitude
         sigma, wv, guard = self.take_pre()
         y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard,
                         out if restore is _identity else None)
@@ -369,6 +370,7 @@ class SelfAttention(nn.Module):
     def forward(self, function_input):
         shape = function_input.shape
         rows = function_input.reshape(shape[0], shape[1], -1)          # [B, C, N]
+        ops.carry_amax(function_input, rows)
         for part in (self.conv_0, self.nlin_0, self.conv_1):
             rows = part(rows)
         return ops.softmax_lastdim(rows).view(shape)

@@ -118,6 +118,16 @@ def _amax_of(t):
     return getattr(t, "_locate_amax", None) if AMAX.enabled else None
 
 
+def carry_amax(src, view):
+    """`view` shows the same elements as `src` (reshape / view of a contiguous tensor): it inherits src's largest-magnitude words,
+    which Python attributes do not do by themselves."""
+    if view is not src and view.numel() == src.numel() and view.data_ptr() == src.data_ptr():
+        a = getattr(src, "_locate_amax", None)
+        if a is not None:
+            view._locate_amax = a
+    return view
+
+
 def tag_amax(t):
     """Computes t's largest-magnitude word with a pass of its own and attaches it (tests, tools; the hot path gets the word from
     the kernel that produces the tensor)."""
