@@ -198,7 +198,15 @@ class _TwoBranch(nn.Module):
             # one tensor, two consumers of this package (the merge itself and the branch's leading norm / RootTanh): their
             # backward kernels share one gradient buffer instead of leaving an add to autograd (ops.fork)
             function_input, feed = ops.fork(function_input)
-        skip = self.residual_module(function_input)
+        stages = list(self.residual_module) if isinstance(self.residual_module, nn.Sequential) else [self.residual_module]
+        if layer_input is None and isinstance(stages[0], CatModule) and stages[0].in_place(function_input):
+            # the discriminator's stem: its input (the generated image in the G-step) feeds the identity half of the skip branch's
+            # concatenation, that branch's 1x1 conv and the conv branch - the three gradients are summed by one launch (ops.fork3)
+            skip, conv_alias, feed = ops.fork3(function_input)
+            for i, stage in enumerate(stages):
+                skip = stage(skip, conv_alias=conv_alias) if (i == 0 and conv_alias is not skip) else stage(skip)
+        else:
+            skip = self.residual_module(function_input)
         branch = self.layer_module(feed) if scale is None else self.layer_module(feed, scale)
         return skip, branch
 
