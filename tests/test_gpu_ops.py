@@ -1186,3 +1186,43 @@ def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fm
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(a).all() and a.abs().max() > 0
         assert_close(b.cpu(), a.cpu(), 1e-6, "direct vs two-pass")
+
+
+@pytest.mark.gpu
+def test_end_of_pass_batches_split_into_chunks():
+    """More deferred weight gradients in one pass than one batched launch takes (locate_wgrad_batch_max / locate_slab_reduce_max
+    records): the runtime launches them in chunks; every gradient equals the un-deferred one bit for bit."""
+    import ctypes
+    from locate_amd import ops
+    from locate_amd._lib import lib
+    L = lib()
+    torch.manual_seed(9)
+    n_small, n_split = L.locate_wgrad_batch_max() + 7, L.locate_slab_reduce_max() + 5
+    rt = ops.Runtime()
+    rt._end_scheduled = True          # no autograd pass here: the end-of-pass work is run by hand below
+    plain = ops.Runtime()
+    plain.defer_finalisers = False
+    jobs = []
+    for i in range(n_small + n_split):
+        small = i < n_small
+        cin, cout = (5 + i % 7, 3 + i % 5) if small else (8 + i % 4, 8)
+        spec = ops.ConvSpec("conv", 1, 1, 1, 0, 0) if small else ops.ConvSpec("conv", 3, 3, 1, 1, 1)
+        x = torch.randn(6, cin, 1, 1, device=dev()) if small else torch.randn(4, cin, 16, 16, device=dev())
+        w = torch.randn((cout, cin) + ((1, 1) if small else (3, 3)), device=dev())
+        geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+        garr = (ctypes.c_int * 12)(*geom)
+        gy = torch.randn(out_shape, device=dev())
+        inv = torch.full((1,), 0.5 + 0.01 * i, device=dev())
+        npart = ops._weight_grad_partials(spec, geom, garr)
+        outs = []
+        for r in (rt, plain):
+            gw = torch.full_like(w, 3.0)
+            part = torch.zeros(npart, dtype=torch.float64, device=dev())
+            ops._raw_weight_grad(spec, geom, garr, x, gy, gw, w, inv, 0, 0, part, 0, None, None, r)
+            outs.append((gw, part))
+        jobs.append(outs)
+    assert len(rt._fin_wgrad) == n_small and len(rt._fin_slab) > L.locate_slab_reduce_max()
+    rt._end_of_backward()
+    torch.cuda.synchronize()
+    for (g1, p1), (g2, p2) in jobs:
+        assert torch.equal(g1, g2) and torch.equal(p1, p2)
