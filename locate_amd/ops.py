@@ -115,7 +115,16 @@ F16_CALLS = {"fwd": 0, "dgrad": 0, "wgrad": 0}      # launches that took the fp1
 
 
 def _amax_of(t):
-    return getattr(t, "_locate_amax", None) if AMAX.enabled else None
+    """The largest-magnitude words of t, or None.  A full view of a tagged tensor (autograd's own reshape of a gradient on its
+    way through a view node) finds them on its base."""
+    if not AMAX.enabled:
+        return None
+    a = getattr(t, "_locate_amax", None)
+    if a is None:
+        base = t._base
+        if base is not None and base.numel() == t.numel() and base.data_ptr() == t.data_ptr():
+            a = getattr(base, "_locate_amax", None)
+    return a
 
 
 def carry_amax(src, view):
