@@ -319,8 +319,10 @@ def main():
         # the D-step's backward runs in two segments cut behind the discriminator's block 2 (maps >= 8x8 | <= 4x4): the deep
         # segment holds ~95 % of D's parameters and is on the wire while the high-resolution segment's backward runs
         d_cut = 3 if len(D.main[1].blocks) > 3 else None
-        red_g = GradAllReducer(G.parameters(), force=force_dp)
-        red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp)
+        solo = int(os.environ.get("LOCATE_DP_SOLO_BYTES", "0"))     # > 0: gradients from this size up are all-reduced in place
+        red_g = GradAllReducer(G.parameters(), force=force_dp, solo_bytes=solo)
+        red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp,
+                               solo_bytes=solo)
     wgrad_overlap = False if (args.no_wgrad_overlap or args.wgrad_overlap == "off") else (True if args.wgrad_overlap == "on" else bool(dp))
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
                      overlap_wgrad=wgrad_overlap, d_cut=d_cut)

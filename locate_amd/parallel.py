@@ -28,7 +28,7 @@ def broadcast_module_state(module, src=0, extra_tensors=()):
 
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, overlap=True, late=None, groups=None, reduce_op=None,
-                 force=False):
+                 force=False, solo_bytes=0):
         """`late`: predicate (or collection) of parameters whose .grad is only assigned at the very end of the backward
         pass, outside autograd's accumulation (the spectral-norm v vectors, ops.Runtime._finalize_dv).  They get buckets
         of their own, all-reduced by finish(), so that they never hold back a bucket of ordinary gradients.
@@ -38,7 +38,12 @@ class GradAllReducer:
         uses, where post-accumulate hooks do not exist.
         `reduce_op`: "avg" (the collective averages: RCCL) or "sum" (sum, then scale by 1 / world on unpack: gloo); default by
         backend.  `force`: run the whole exchange - buckets, side stream, collective, unpack - at world size 1 as well (a
-        one-rank rehearsal of the RCCL path on a single GPU; otherwise a lone rank skips it)."""
+        one-rank rehearsal of the RCCL path on a single GPU; otherwise a lone rank skips it).
+        `solo_bytes` (default 0: off): a gradient of at least this size is a bucket of its own and is all-reduced IN PLACE - no
+        copy into a flat buffer and back (at config 2 four generator and five discriminator weights are ~90 % of the 103 MB
+        payload).  Measured only in the one-rank RCCL rehearsal, where it LOSES (10.23 -> 10.40 ms per step: nine more
+        collectives cost more launch latency than 0.2 ms of copy traffic on the side stream saves); whether it pays over xGMI at
+        8 ranks is open, hence opt-in (bench.py: LOCATE_DP_SOLO_BYTES)."""
         self.params = [p for p in params]
         if late is None:
             is_late = [False] * len(self.params)
@@ -72,6 +77,8 @@ class GradAllReducer:
         # reverse order ~ gradient production order
         self.buckets = []          # list of lists of parameter indices
         self.bucket_group = []     # segment group of each bucket
+        self.bucket_solo = []      # one large gradient, reduced in place
+        solo_bytes = int(solo_bytes or 0)
         for gi in range(self.n_groups):
             for group_late in (False, True):
                 cur, cur_bytes = [], 0
@@ -80,15 +87,28 @@ class GradAllReducer:
                         continue
                     p = self.params[idx]
                     nbytes = p.numel() * p.element_size()
+                    if solo_bytes and nbytes >= solo_bytes:
+                        # in production order: the packed bucket under construction is closed first
+                        if cur:
+                            self.buckets.append(cur)
+                            self.bucket_group.append(gi)
+                            self.bucket_solo.append(False)
+                            cur, cur_bytes = [], 0
+                        self.buckets.append([idx])
+                        self.bucket_group.append(gi)
+                        self.bucket_solo.append(True)
+                        continue
                     if cur and cur_bytes + nbytes > bucket_bytes:
                         self.buckets.append(cur)
                         self.bucket_group.append(gi)
+                        self.bucket_solo.append(False)
                         cur, cur_bytes = [], 0
                     cur.append(idx)
                     cur_bytes += nbytes
                 if cur:
                     self.buckets.append(cur)
                     self.bucket_group.append(gi)
+                    self.bucket_solo.append(False)
         # RCCL averages in the collective itself; gloo (CPU tests, single-GPU rehearsals) sums and scales afterwards
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         if reduce_op not in (None, "avg", "sum"):
@@ -162,10 +182,14 @@ class GradAllReducer:
         grads = [self.params[i].grad for i in members]
         dev = grads[0].device
         total = sum(g.numel() for g in grads)
-        flat = self._flat[b]
-        if flat is None or flat.numel() != total or flat.device != dev:
-            flat = torch.empty(total, dtype=grads[0].dtype, device=dev)
-            self._flat[b] = flat
+        in_place = self._in_place(b, grads)
+        if in_place:
+            flat = grads[0].view(-1)            # the gradient itself: reduced where it lies
+        else:
+            flat = self._flat[b]
+            if flat is None or flat.numel() != total or flat.device != dev:
+                flat = torch.empty(total, dtype=grads[0].dtype, device=dev)
+                self._flat[b] = flat
         if dev.type == "cuda":
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -175,12 +199,17 @@ class GradAllReducer:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record(self._side)
                     self._t_comm.append([ev, None])
-                self._pack(b, flat, grads)
+                if not in_place:
+                    self._pack(b, flat, grads)
                 work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         else:
-            self._pack(b, flat, grads)
+            if not in_place:
+                self._pack(b, flat, grads)
             work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
-        self._handles.append((b, members, work))
+        self._handles.append((b, members, work, flat if in_place else None))
+
+    def _in_place(self, b, grads):
+        return self.bucket_solo[b] and len(grads) == 1 and grads[0].is_contiguous()
 
     def _check_agreement(self, b, members):
         """Which parameters have a gradient is decided per rank (`grad is not None`); ranks that disagreed would exchange
@@ -276,13 +305,16 @@ class GradAllReducer:
             if not self._launched[b]:
                 self._launch(b)
         inv = None if self._avg else 1.0 / self.world
-        for b, members, work in self._handles:
-            flat = self._flat[b]
+        for b, members, work, own in self._handles:
+            flat = own if own is not None else self._flat[b]
             dev = flat.device
             if dev.type == "cuda":
                 with torch.cuda.stream(self._side):
                     work.wait()
-                    self._unpack(b, flat, members, inv)
+                    if own is None:
+                        self._unpack(b, flat, members, inv)
+                    elif inv is not None:
+                        own.mul_(inv)
                     if self.timing:
                         ev = torch.cuda.Event(enable_timing=True)
                         ev.record(self._side)
@@ -292,7 +324,10 @@ class GradAllReducer:
                                 break
             else:
                 work.wait()
-                self._unpack(b, flat, members, inv)
+                if own is None:
+                    self._unpack(b, flat, members, inv)
+                elif inv is not None:
+                    own.mul_(inv)
         if self._side is not None:
             cur = torch.cuda.current_stream(self._side.device)
             if self.timing:
@@ -326,12 +361,18 @@ class GradAllReducer:
             if not members:
                 continue
             grads = [self.params[i].grad for i in members]
+            self._check_agreement(b, members)
+            if self._in_place(b, grads):
+                own = grads[0].view(-1)
+                dist.all_reduce(own, op=self._op(), group=self.group)
+                if inv is not None:
+                    own.mul_(inv)
+                continue
             total = sum(g.numel() for g in grads)
             flat = self._flat[b]
             if flat is None or flat.numel() != total or flat.device != grads[0].device:
                 flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
                 self._flat[b] = flat
-            self._check_agreement(b, members)
             self._pack(b, flat, grads)
             dist.all_reduce(flat, op=self._op(), group=self.group)
             self._unpack(b, flat, members, inv)

@@ -18,7 +18,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, bucket_bytes, overlap, q):
+def _worker(rank, world, port, bucket_bytes, overlap, q, solo_bytes=0):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
         late = torch.nn.Parameter(torch.randn(3))              # like D's spectral-norm v: .grad assigned after backward
         broadcast_module_state(torch.nn.ParameterList([late]), 0)
         params = list(net.parameters()) + [unused, frozen, late]
-        red = GradAllReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, late=[late])
+        red = GradAllReducer(params, bucket_bytes=bucket_bytes, overlap=overlap, late=[late], solo_bytes=solo_bytes)
         torch.manual_seed(7)                                  # same data stream on both ranks, shard by rank
         x = torch.randn(8, 6)
         shard = x[rank * 4:(rank + 1) * 4]
@@ -80,28 +80,32 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
         gathered = [None] * world
         dist.all_gather_object(gathered, [t.tolist() for t in w0])
         same_weights = gathered[0] == gathered[1]
-        q.put((rank, ok, same_weights, len(red.buckets)))
+        q.put((rank, ok, same_weights, len(red.buckets), sum(red.bucket_solo)))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, False, False, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("bucket_bytes,overlap", [(32 << 20, True), (64, True), (64, False)])
-def test_grad_allreduce_world2(bucket_bytes, overlap):
+@pytest.mark.parametrize("bucket_bytes,overlap,solo_bytes", [(32 << 20, True, 0), (64, True, 0), (64, False, 0),
+                                                             (32 << 20, True, 60), (64, False, 60)])
+def test_grad_allreduce_world2(bucket_bytes, overlap, solo_bytes):
+    """solo_bytes = 60: the two weight matrices (120 and 60 bytes) are buckets of their own, all-reduced in place (sum, then scaled:
+    gloo), between packed buckets of the biases - hook-driven, flushed by finish(), and in reduce_now()."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, overlap, q, solo_bytes)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    for rank, ok, same, info in res:
-        assert ok and same, (rank, info)
+    for r in res:
+        assert r[1] and r[2], r
     if bucket_bytes == 64:
         assert res[0][3] > 1        # several buckets were exercised
+    assert res[0][4] == (2 if solo_bytes == 60 else 0)        # in-place buckets
 
 
 def test_single_process_is_a_no_op():
