@@ -312,21 +312,26 @@ def test_step_vs_oracle_on_unusual_shapes(S, B, ff, stacked, switches):
         assert_step_close(gsd[k].cpu(), v, cfg.glr, 1, "G post " + k)
 
 
-@pytest.mark.parametrize("mode", ["stacked", "stacked+wgrad-stream", "three-streams"])
-def test_graph_replay_equals_eager(mode):
+@pytest.mark.parametrize("mode", ["stacked", "stacked+wgrad-stream", "three-streams", "stacked+early-second-pass"])
+def test_graph_replay_equals_eager(mode, monkeypatch):
     """hipGraph replay of the captured phases must produce the same trajectory as eager launches - BIT FOR BIT: the kernels are
     deterministic (no atomics on values; split-K partial sums are added in a fixed order) and a replay launches exactly the
     kernels the eager iteration does.  Modes: the stacked D-step (what bench.py runs), the same with the weight gradients on
     a second stream, and the three-stream D-step, whose three discriminator passes are parallel branches of ONE graph and must
-    not share split-K arrival counters (ops._counters)."""
+    not share split-K arrival counters (ops._counters); and the opt-in schedule LOCATE_G2_EARLY=1 - the generator's two power
+    iterations hoisted into a graph of their own, both generator passes replayed concurrently, the second on its own counter
+    lane (graph.py)."""
     from locate_amd.graph import GraphedTrainStep
     z = load_golden("g8_tiny_e2e")
     kw = {"stacked": dict(stacked_d=True), "stacked+wgrad-stream": dict(stacked_d=True, overlap_wgrad=True),
-          "three-streams": dict(concurrent_d=True)}[mode]
+          "three-streams": dict(concurrent_d=True), "stacked+early-second-pass": dict(stacked_d=True)}[mode]
+    if mode == "stacked+early-second-pass":
+        monkeypatch.setenv("LOCATE_G2_EARLY", "1")
     cfg, G1, D1, step1, dev = _build_tiny(z, True, **kw)    # same arithmetic, launched eagerly
     _, G2, D2, step2, _ = _build_tiny(z, True, **kw)
     lat, real, aug = (T(z["step1/" + k]).to(dev) for k in ("latent", "real", "aug"))
     runner = GraphedTrainStep(step2, lat, real, aug, warmup=2)      # 2 eager iterations, then capture (no execution)
+    assert (runner.begin_graph is not None) == (mode == "stacked+early-second-pass")
     for _ in range(2):
         out1 = step1(lat, real, aug)
     for _ in range(3):                                               # three replays
