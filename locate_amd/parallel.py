@@ -248,9 +248,13 @@ class GradAllReducer:
         stream (the next segment's backward, replayed right after this call, runs beside them)."""
         if not self.enabled:
             return
+        first = len(self._handles)
         for b, g in enumerate(self.bucket_group):
             if g == gi and not self._launched[b]:
                 self._launch(b)
+        # their results go back into the .grad tensors as soon as each collective is done - on the side stream, beside the next
+        # segment's backward - instead of at finish(), where the compute stream would wait for the copies as well
+        self._unpack_handles(first)
 
     @staticmethod
     def _views(flat, grads):
@@ -304,8 +308,27 @@ class GradAllReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        self._unpack_handles(0)
+        if self._side is not None:
+            cur = torch.cuda.current_stream(self._side.device)
+            if self.timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self._side)
+                b.record(cur)
+                self._t_wait.append((a, b))
+            else:
+                cur.wait_stream(self._side)
+        self._handles = []
+
+    def _unpack_handles(self, first):
+        """Wait (stream-ordered on the GPU) for the collectives launched since handle `first` and scatter their results."""
         inv = None if self._avg else 1.0 / self.world
-        for b, members, work, own in self._handles:
+        for k in range(first, len(self._handles)):
+            if self._handles[k] is None:
+                continue
+            b, members, work, own = self._handles[k]
+            self._handles[k] = None
             flat = own if own is not None else self._flat[b]
             dev = flat.device
             if dev.type == "cuda":
@@ -328,17 +351,6 @@ class GradAllReducer:
                     self._unpack(b, flat, members, inv)
                 elif inv is not None:
                     own.mul_(inv)
-        if self._side is not None:
-            cur = torch.cuda.current_stream(self._side.device)
-            if self.timing:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(cur)
-                cur.wait_stream(self._side)
-                b.record(cur)
-                self._t_wait.append((a, b))
-            else:
-                cur.wait_stream(self._side)
-        self._handles = []
 
     def pop_timing(self):
         """(side-stream milliseconds spent on the exchange, milliseconds the compute stream waited for it) since the last
