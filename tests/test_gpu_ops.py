@@ -1226,3 +1226,43 @@ def test_end_of_pass_batches_split_into_chunks():
     torch.cuda.synchronize()
     for (g1, p1), (g2, p2) in jobs:
         assert torch.equal(g1, g2) and torch.equal(p1, p2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f16", [True, False])
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,H,B", [("convT", 768, 768, 4, 2, 1, 4, 64), ("convT", 96, 96, 4, 2, 1, 32, 64),
+                                                      ("conv", 48, 48, 3, 1, 1, 64, 64), ("conv", 128, 128, 5, 2, 2, 8, 192)])
+def test_conv_adjointness_at_benchmark_size(kind, cin, cout, k, s, p, H, B, f16):
+    """Size-independent property at BASELINE's full sizes, tying the three kernels of a layer together: with y = f(x; W),
+    <g, f(x)> = <f^T(g), x> (forward against input gradient) = <dW(x, g), W> (against the weight gradient) - f is bilinear in
+    (x, W).  In both fp32-faithful forms (fp16 pieces when the operands carry their largest magnitude, bf16 pieces otherwise);
+    sums in float64, bound 2e-6 of sum |g f(x)| (the forms' own error is a few 1e-7 per element, uncorrelated)."""
+    from locate_amd import ops
+    torch.manual_seed(cin + k + H)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w = (torch.randn(wshape, device=dev()) * 0.05).requires_grad_(True)
+    rows = wshape[0]
+    u, v = torch.randn(rows, device=dev()), torch.randn(w.numel() // rows, device=dev())
+    sigma, wv = torch.tensor([1.0, 1.0], device=dev()), torch.zeros(rows, device=dev())      # sigma = 1: f is the bare layer
+    spec = ops.ConvSpec(kind, k, k, s, p, p)
+    x = torch.randn(B, cin, H, H, device=dev())
+    if f16:
+        ops.tag_amax(x)
+    x.requires_grad_(True)
+    before = dict(ops.F16_CALLS)
+    y = ops.SNConvFn.apply(x, w, u, v, None, sigma, wv, spec)
+    g = torch.randn_like(y)
+    if f16:
+        ops.tag_amax(g)
+    y.backward(g)
+    took = {kk: ops.F16_CALLS[kk] - before[kk] for kk in before}
+    assert took == ({"fwd": 1, "dgrad": 1, "wgrad": 1} if f16 else {"fwd": 0, "dgrad": 0, "wgrad": 0}), took
+    lhs = float((g.double() * y.detach().double()).sum())
+    scale = float((g.double() * y.detach().double()).abs().sum())
+    via_x = float((x.grad.double() * x.detach().double()).sum())
+    # the weight gradient carries the spectral-norm correction d(sigma) u v^T with d(sigma) = -<G, W> / sigma^2; with sigma = 1:
+    # <dW_total, W> = <G, W> - <G, W> <u v^T, W>, so <G, W> = <dW_total, W> / (1 - <u v^T, W>)
+    uvw = float((torch.outer(u, v).double() * w.detach().double().view(rows, -1)).sum())
+    via_w = float((w.grad.double() * w.detach().double()).sum()) / (1.0 - uvw)
+    assert abs(via_x - lhs) <= 2e-6 * scale, (lhs, via_x, scale)
+    assert abs(via_w - lhs) <= 2e-6 * scale * max(1.0, abs(1.0 / (1.0 - uvw))), (lhs, via_w, scale, uvw)
