@@ -1266,3 +1266,45 @@ def test_conv_adjointness_at_benchmark_size(kind, cin, cout, k, s, p, H, B, f16)
     via_w = float((w.grad.double() * w.detach().double()).sum()) / (1.0 - uvw)
     assert abs(via_x - lhs) <= 2e-6 * scale, (lhs, via_x, scale)
     assert abs(via_w - lhs) <= 2e-6 * scale * max(1.0, abs(1.0 / (1.0 - uvw))), (lhs, via_w, scale, uvw)
+
+
+@pytest.mark.gpu
+def test_linear_stencils_are_adjoint_pairs_at_benchmark_size():
+    """Size-independent property at config 2's own tensor sizes (batch 64): every linear resampling operator and its backward
+    kernel are adjoint - <op(x), y> = <x, op^T(y)> - for the bilinear x2 upsample (all three kernel variants' sizes), the 2x2
+    mean and the channel pooling of the skip branch; sums in float64."""
+    from locate_amd import ops
+    torch.manual_seed(21)
+    cases = [("upsample 96@32", lambda t: ops.upsample2x(t), (64, 96, 32, 32)), ("upsample 768@4", lambda t: ops.upsample2x(t), (64, 768, 4, 4)),
+             ("upsample 384@8", lambda t: ops.upsample2x(t), (64, 384, 8, 8)), ("avgpool 32@64 [3B]", lambda t: ops.avgpool2(t), (192, 32, 64, 64)),
+             ("avgpool 512@2", lambda t: ops.avgpool2(t), (192, 512, 2, 2)), ("feature pool 96->48@64", lambda t: ops.feature_pool(t, 48), (64, 96, 64, 64)),
+             ("feature pool 768->384@8", lambda t: ops.feature_pool(t, 384), (64, 768, 8, 8))]
+    for name, op, shape in cases:
+        x = torch.randn(shape, device=dev(), requires_grad=True)
+        y = op(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        lhs = float((y.detach().double() * g.double()).sum())
+        rhs = float((x.grad.double() * x.detach().double()).sum())
+        scale = float((y.detach().double() * g.double()).abs().sum())
+        assert abs(lhs - rhs) <= 1e-6 * scale, (name, lhs, rhs, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_act", [False, True])
+def test_inplace_norm_gradient_annihilates_shift_and_scale_at_benchmark_size(with_act):
+    """Size-independent property at config 2's largest norm input (64 x 96 x 64 x 64): out = norm(x) is invariant under x -> a x + b
+    (a > 0) for its GLOBAL statistics, so the input gradient is orthogonal to the all-ones tensor and to x itself - whatever the
+    scale, the bias, the following RootTanh and the incoming gradient are.  Float64 sums; bound 2e-6 of sum |gx x|."""
+    from locate_amd import ops
+    torch.manual_seed(33)
+    x = (torch.randn(64, 96, 64, 64, device=dev()) * 1.7 + 0.4).requires_grad_(True)
+    scale = torch.randn(1, 96, 1, 1, device=dev()) * 0.5 + 1.0
+    bias = torch.randn(1, 96, 1, 1, device=dev()) * 0.3
+    y = ops.inplace_norm(x, scale, bias, with_act=with_act)
+    g = torch.randn_like(y)
+    y.backward(g)
+    gx, xd = x.grad.double(), x.detach().double()
+    ref = float((gx * xd).abs().sum())
+    assert abs(float(gx.sum())) <= 2e-6 * float(gx.abs().sum())
+    assert abs(float((gx * xd).sum())) <= 2e-6 * ref
