@@ -213,9 +213,19 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
     const int k0 = bx * 64, m0 = by * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     float am = 0.0f;
+    // this thread's reduction index k = (c, th, tw) inside a weight row [C][KH][KW]: k itself when the panel holds every tap, else
+    // the tap sub-rectangle's position (layers whose maps mostly see padding: the reads then stay inside each channel's window)
+    const int k = k0 + tx, T = a.TH * a.TW;
+    int src = k;
+    if (T != a.KH * a.KW && k < a.K) {
+        const int c = k / T, t = k - c * T;
+        const int th = t / a.TW, tw = t - th * a.TW;
+        src = (c * a.KH + a.kh0 + th) * a.KW + a.kw0 + tw;
+    }
+    const int64_t wrow = (int64_t)a.C * a.KH * a.KW;
     for (int j = ty; j < 64; j += 4) {
-        const int m = m0 + j, k = k0 + tx;
-        const float v = (m < a.M && k < a.K) ? a.w[(int64_t)m * a.K + k] : 0.0f;
+        const int m = m0 + j;
+        const float v = (m < a.M && k < a.K) ? a.w[(int64_t)m * wrow + src] : 0.0f;
         tile[j][tx] = v;
         am = fmaxf(am, fabsf(v));
     }
@@ -466,7 +476,7 @@ static PackJob make_pack_job(const PackBatch& b, int nphase) {
     PackJob j;
     j.batch = b; j.nphase = nphase; j.block_start = 0; j.pad = 0;
     const PackArgs& a0 = b.ph[0];
-    if (a0.mode == 0 && nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW) {
+    if (a0.mode == 0 && nphase == 1) {
         j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS && a0.direct) {
         j.kind = 3; j.gx = (a0.ld + packd_cs(a0.KH * a0.KW) - 1) / packd_cs(a0.KH * a0.KW); j.gy = (a0.M + PACKD_MB - 1) / PACKD_MB;
@@ -1803,7 +1813,7 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
     LOCATE_REQUIRE(p.nphase > 0, "locate_conv_pack_job: empty panel");
     if (direct && (weight_absmax || !(adjoint & 2))) {
         const PackArgs& a0 = batch.ph[0];
-        const bool transpose = a0.mode == 0 && p.nphase == 1 && a0.TH == a0.KH && a0.TW == a0.KW;
+        const bool transpose = a0.mode == 0 && p.nphase == 1;
         const bool adj = a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS;
         if (transpose || adj) {
             // single-tap panels feed the pointwise / 1x1-map kernels, which read the fp32 rows; the debug library's fp32-MFMA
