@@ -166,10 +166,21 @@ size_t locate_conv_pack_job_bytes(void);
  * with the largest magnitude of w as it is now (locate_nadam_step leaves them per tensor); else the two-pass form is taken */
 int locate_conv_pack_job(const int* geom, int adjoint, const float* w, float* panel, int block_start, void* job_out,
                          int* blocks_out, int direct, const void* weight_absmax);
-/* any_f16: some job is a two-pass fp16-piece panel; any_two_pass: some job is in the two-pass form at all (both 0 when every
- * job took the direct form, locate_conv_pack_job_is_direct: then the whole re-packing is one launch) */
-int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int any_two_pass, void* stream);
+/* any_f16: some job is a non-direct fp16-piece panel (its absmax header is cleared first); passes: bit 0 = some gather-kernel
+ * panel is in the two-pass form (split launch), bit 1 = some WINDOW panel of fp16 pieces came without absmax words (absmax
+ * pre-pass into the panel headers); both 0 when every job took the direct form (locate_conv_pack_job_is_direct): one launch */
+int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int passes, void* stream);
 int locate_conv_pack_job_is_direct(const void* job);
+int locate_conv_pack_job_is_window(const void* job);
+/* ---- window form of the dense contractions (csrc/convwin.hip): the gathered operand is staged in LDS once per block and 8
+ *      reduction channels as the raw window of the map its 128 output columns see, every tap's MFMA fragment is read from that
+ *      one image (libs/conv.py:14-20's k x k convs, both directions; the 1x1 contractions of libs/scale.py:25-34,
+ *      libs/attention.py:44-46).  locate_conv_win_ok(geom, adjoint | fmt, x_bs, x): 1 when this geometry / direction / operand
+ *      alignment has the form.  The caller then uses panel format bit 2 (`adjoint | fmt | 4`) in locate_conv_panel_bytes /
+ *      _pack_panel / _pack_job, passes `precision | 16` to locate_conv_fwd / locate_conv_dgrad and sizes the split-K workspace
+ *      with locate_conv_win_workspace_bytes.  Same arithmetic and accuracy as the gather kernels at each precision. ---- */
+int locate_conv_win_ok(const int* geom, int adjoint_fmt, int64_t x_bs, const void* x);
+size_t locate_conv_win_workspace_bytes(const int* geom, int adjoint_fmt);
 size_t locate_conv_fwd_workspace_bytes(const int* geom);
 /* arrival counters for split-K launches that combine their partial tiles INSIDE the launch (the tile's last-arriving block
  * sums them in a fixed order: bit-reproducible): locate_conv_counter_bytes() bytes of device memory, zero before their first

@@ -79,6 +79,9 @@ PROTOTYPES = {
     "locate_conv_pack_job": (c_i, [c_ip, c_i, c_p, c_p, c_i, c_p, c_ip, c_i, c_p]),
     "locate_conv_pack_panels": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p]),
     "locate_conv_pack_job_is_direct": (c_i, [c_p]),
+    "locate_conv_pack_job_is_window": (c_i, [c_p]),
+    "locate_conv_win_ok": (c_i, [c_ip, c_i, c_i64, c_p]),
+    "locate_conv_win_workspace_bytes": (c_sz, [c_ip, c_i]),
     "locate_conv_fwd_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_counter_bytes": (c_sz, []),
     "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p, c_p]),
@@ -127,7 +130,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 7
+EXPECTED_ABI = 8
 
 
 _lib = None

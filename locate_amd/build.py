@@ -14,9 +14,9 @@ LIB = os.path.join(CSRC, "liblocate_hip.so")
 # switch used by tests/test_gpu_ops.py::test_bf16x6_kernels_match_fp32_mfma_kernels and the A/B tools).  Loaded only when
 # LOCATE_HIP_DEBUG_LIBRARY=1 is set before `import locate_amd`; the product library has no such switch compiled in.
 LIB_DBG = os.path.join(CSRC, "liblocate_hip_dbg.so")
-DBG_SOURCES = ["conv.hip"]
-SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "grouped.hip",
-           "nadam.hip", "loss.hip", "finalise.hip", "parallel.hip"]
+DBG_SOURCES = ["conv.hip", "convwin.hip"]
+SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "convwin.hip",
+           "grouped.hip", "nadam.hip", "loss.hip", "finalise.hip", "parallel.hip"]
 ARCH = "gfx950"
 
 
@@ -31,11 +31,16 @@ def _sources():
     return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _headers():
+    """every header under csrc/: an edit to any of them rebuilds every object (they are few and small)"""
+    return [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+
+
 def needs_build():
     if not (os.path.exists(LIB) and os.path.exists(LIB_DBG)):
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_DBG))
-    deps = [os.path.join(CSRC, s) for s in _sources()] + [os.path.join(CSRC, "common.h")]
+    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -47,7 +52,7 @@ def build(force=False, verbose=True):
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
              "-I", CSRC]
     procs = []
-    hdr_time = os.path.getmtime(os.path.join(CSRC, "common.h"))
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
     for src in _sources():
         path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))

@@ -20,94 +20,9 @@
 //
 // Tiling: 256 threads = 4 waves, block tile BM x 128 (BM in {128, 96, 64, 32}), K step 16, double-buffered
 // LDS with register prefetch of the next K step, one barrier per step.
-#include "common.h"
-#include <cstdlib>
-#include <cstring>
-#include <stdlib.h>
-#include <type_traits>
+#include "igemm.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define IG_BK 16            // K elements per main-loop step
-#define IG_KPAD 32          // panels are zero-padded to a multiple of this many K rows
-#define IG_TAIL 112         // extra zero rows after Kpad: the branch-free prefetch of the last steps stays in bounds
-#define IG_MAXT 32
-
-struct ConvGeom {
-    int B, C, H, W;            // input of R
-    int M, KH, KW;             // weight [M, C, KH, KW]
-    int stride, pad_h, pad_w;
-    int OH, OW;                // output of R
-};
-
-static int geom_check(const ConvGeom& g, const char* who) {
-    LOCATE_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0 && g.M > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0,
-                   "%s: non-positive dimension", who);
-    LOCATE_REQUIRE(g.KH * g.KW <= IG_MAXT - 7, "%s: kernel %dx%d has more than %d taps", who, g.KH, g.KW, IG_MAXT - 7);
-    LOCATE_REQUIRE(g.stride <= 2, "%s: stride %d unsupported (1 or 2)", who, g.stride);
-    LOCATE_REQUIRE(g.OH == (g.H + 2 * g.pad_h - g.KH) / g.stride + 1 && g.OW == (g.W + 2 * g.pad_w - g.KW) / g.stride + 1,
-                   "%s: output size %dx%d does not match the geometry", who, g.OH, g.OW);
-    LOCATE_REQUIRE((int64_t)g.B * g.C * g.H * g.W < (1ll << 31) && (int64_t)g.B * g.M * g.OH * g.OW < (1ll << 31),
-                   "%s: tensor larger than 2^31 elements", who);
-    return LOCATE_OK;
-}
-
-static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
-
-// ---------------------------------------------------------------------------------------------
-// Weight panel of one phase (all sections in 4-byte units, one buffer):
-//   weights [rows][ld]   K-major, rows = Kpad + IG_TAIL, zero beyond K and beyond M
-//   koff    [rows]       int: BYTE offset of gathered row k = (c, t) inside one batch image of the gathered tensor,
-//                        4 (c*H*W + dy(t)*W + dx(t) - dmin), dmin = the most negative tap displacement, so that the
-//                        offsets are >= 0 (they go into the scalar offset of a buffer load whose descriptor starts
-//                        dmin elements before the tensor; 0 beyond K)
-//   ktap    [rows / 4]   bytes: tap index t of row k (31 beyond K: a tap that is never valid)
-//   w3      [3][rows / 8][ld][8]  bf16: the weights as three bf16 pieces w = h + m + l (exact), 8 consecutive k per
-//                        16-byte chunk = the A fragment of v_mfma_f32_32x32x16_bf16
-// The offset table turns the gather's per-element mixed-radix arithmetic (~230 ALU instructions per K step, which
-// cost a quarter of the kernel's throughput) into two wave-uniform scalar loads per step.
-// ---------------------------------------------------------------------------------------------
-struct PackArgs {
-    const float* w;       // [M, C, KH, KW]
-    float* out;           // phase panel
-    int M, C, KH, KW;
-    int mode;             // 0: rows k=(c,kh,kw), cols m          (R forward)
-                          // 1: rows k=(m,th,tw), cols c, taps kh = kh0 + s*th, kw = kw0 + s*tw   (R data-adjoint phase)
-    int kh0, kw0, s, TH, TW;
-    int K, rows, ld;
-    int gHW, gW, dy0, dys, dx0, dxs;   // geometry of the gathered tensor and of the tap grid
-    int dmin;                          // min over the taps of dy*gW + dx (<= 0)
-    int fmt;                           // split section: 0 = three bf16 planes, 1 = header + two fp16 planes
-    // DIRECT re-packing (fmt 1 only): the weights' largest magnitude is already known (AMAX_WORDS words left by the optimizer
-    // kernel, nadam.hip), so the packing blocks write the two scaled fp16 planes themselves - no second pass over an fp32
-    // intermediate - and, where no kernel reads the K-major fp32 rows (every panel but single-tap ones: pointwise / 1x1-map
-    // kernels), do not write those either.  The offset tables and zero tails of an earlier full packing stay as they are.
-    const unsigned* wmax;              // fmt 1, direct form: the weights' absmax words
-    int direct;                        // 0: the two-pass form (fp32 rows, maximum folded in while packing, split pass)
-    int keep_f32;                      // direct form: also refresh the fp32 rows
-};
-
-// fmt 0: the split section holds the three bf16 planes; fmt 1 ("fp16 pieces", see conv_igemm_bx6_kernel NP = 2): a 4-dword
-// header {absmax bits of this phase's weights, 0, 0, 0} followed by TWO fp16 planes of the weights times 2^k(absmax)
-#define PANEL_HDR 4
-static inline size_t panel_floats(int rows, int ld, int fmt) {
-    return (size_t)rows * ld + rows + rows / 4 + (fmt ? PANEL_HDR + (size_t)rows * ld / 2 * 2 : (size_t)rows * ld / 2 * 3);
-}
-static inline size_t panel_split_offset(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }   // floats
-__device__ __forceinline__ size_t panel_split_offset_dev(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }
-
-// Scale exponent of a tensor whose largest magnitude has the fp32 bit pattern `bits`: k with absmax * 2^k in [2^14, 2^15)
-// - one binade below fp16's largest finite value, so that the two fp16 pieces of every element (11 + 11 significant bits)
-// stay normal numbers down to elements 2^-17 of the largest (below that the low piece goes subnormal: absolute error
-// <= 2^-25 on the scaled tensor, i.e. 2^-39 of its largest element).  Zero / denormal tensors: k = 0.  Clamped so that
-// 2^k and 2^-k are normal fp32 numbers.
-__host__ __device__ __forceinline__ int f16_scale_exp(unsigned bits) {
-    const int e = (int)((bits >> 23) & 0xffu) - 127;
-    if (e == -127) return 0;
-    const int k = 14 - e;
-    return k > 100 ? 100 : (k < -100 ? -100 : k);
-}
-__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }      // -126 <= k <= 127
 
 struct PackBatch {
     PackArgs ph[4];
@@ -362,77 +277,11 @@ __device__ __forceinline__ void pack_adjoint_body(const PackBatch& batch, int np
     }
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// x = h + m + l exactly (3 x 8 significant bits cover fp32's 24): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
-__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = (__bf16)v[j];
-        const float r1 = v[j] - (float)h[j];
-        m[j] = (__bf16)r1;
-        l[j] = (__bf16)(r1 - (float)m[j]);
-    }
-}
-
-// The same exact decomposition by TRUNCATION for the in-loop splits: h = the top 16 bits of x (8 significant bits), r = x - h
-// (exact), m = the top 16 bits of r, l = r - m (at most 8 significant bits left, so its top 16 bits hold all of it).  Bit masks,
-// two subtractions and one byte permute per bf16 pair instead of three conversions and two shifts per element.
-__device__ __forceinline__ void split3_trunc_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
-    const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned q0 = __builtin_bit_cast(unsigned, r0), q1 = __builtin_bit_cast(unsigned, r1);
-    const float l0 = r0 - __builtin_bit_cast(float, q0 & 0xffff0000u), l1 = r1 - __builtin_bit_cast(float, q1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);            // (hi16(v1) << 16) | hi16(v0)
-    m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l0), 0x07060302u);
-}
-
-// two fp32 values rounded to nearest-even bf16, packed (v0 in the low half)
-__device__ __forceinline__ unsigned round_bf16_pair(float v0, float v1) {
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    bf16x2_t r;
-    r[0] = (__bf16)v0;
-    r[1] = (__bf16)v1;
-    return *reinterpret_cast<unsigned*>(&r);
-}
-
-__device__ __forceinline__ void split3_trunc_x8(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
-    split3_trunc_pair(v[0], v[1], h.x, m.x, l.x);
-    split3_trunc_pair(v[2], v[3], h.y, m.y, l.y);
-    split3_trunc_pair(v[4], v[5], h.z, m.z, l.z);
-    split3_trunc_pair(v[6], v[7], h.w, m.w, l.w);
-}
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// x * 2^k = h + l up to 2^-22 |x| with h = fp16(x 2^k), l = fp16(x 2^k - h), both rounded to nearest even
-__device__ __forceinline__ void split2_f16x8(const float (&v)[8], float sc, uint4& h, uint4& l) {
-    f16x8 hh, ll;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = v[j] * sc;
-        hh[j] = (_Float16)x;
-        ll[j] = (_Float16)(x - (float)hh[j]);
-    }
-    h = *reinterpret_cast<uint4*>(&hh);
-    l = *reinterpret_cast<uint4*>(&ll);
-}
-
-// the same for one pair of values, packed (v0 in the low halves)
-__device__ __forceinline__ void split2_f16_pair(float v0, float v1, unsigned& h, unsigned& l) {
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    f16x2 hh, ll;
-    hh[0] = (_Float16)v0; hh[1] = (_Float16)v1;
-    ll[0] = (_Float16)(v0 - (float)hh[0]); ll[1] = (_Float16)(v1 - (float)hh[1]);
-    h = *reinterpret_cast<unsigned*>(&hh);
-    l = *reinterpret_cast<unsigned*>(&ll);
-}
 
 // second packing pass: the fp32 K-major rows of a panel -> its three bf16 planes (16-byte chunks of 8 consecutive k), or
 // its two scaled fp16 planes
 __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int nbx) {
-    if (a.direct) return;              // direct form: the packing blocks wrote the planes
+    if (a.direct || a.win) return;     // direct form / window panels: the packing blocks wrote the planes
     const float* w = a.out;
     uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
     const int64_t total = (int64_t)(a.rows / 8) * a.ld;
@@ -464,6 +313,100 @@ __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window panels (PackArgs::win; convwin.hip): chunk rows in unit order u = c8g * Tp + t - the 8 reduction channels of group c8g
+// at tap t - piece planes only.  A block stages RG reduction channels x CS columns x all taps of the weight tensor in LDS
+// (contiguous runs: RG KK floats per column in the regular direction, CS KK floats per reduction channel in the adjoint one)
+// and writes, for every phase, the chunks (t, c8) of its columns; the last row of blocks also writes the zero rows behind the
+// last unit.  Always one pass: the scale of fp16-piece planes comes from the optimizer's absmax words or from the panel's own
+// header (win_absmax_jobs_kernel ran first).  virtual grid (ceil(ld / CS), ceil(reduction channels / RG)).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_win_emit(const PackArgs& a, const float (&v)[8], float sc, int64_t i) {
+    const int64_t plane = (int64_t)a.urows * a.ld;
+    uint4* w3 = reinterpret_cast<uint4*>(a.out + PANEL_HDR);
+    if (a.fmt) {
+        uint4 h, l;
+        split2_f16x8(v, sc, h, l);
+        w3[i] = h;
+        w3[plane + i] = l;
+    } else {
+        bf16x8 h, m, l;
+        split3_bf16x8(v, h, m, l);
+        w3[i] = *reinterpret_cast<uint4*>(&h);
+        w3[plane + i] = *reinterpret_cast<uint4*>(&m);
+        w3[2 * plane + i] = *reinterpret_cast<uint4*>(&l);
+    }
+}
+
+__device__ __forceinline__ void pack_win_body(const PackBatch& batch, int nphase, int bx, int by, int gy, float* lds) {
+    const PackArgs& a0 = batch.ph[0];
+    const int KK = a0.KH * a0.KW, S = KK | 1;
+    const int CS = KK <= 4 ? 64 : (KK <= 16 ? 32 : 16), RG = win_pack_rg(KK);
+    const int Cred = a0.mode == 0 ? a0.C : a0.M, ncol = a0.mode == 0 ? a0.M : a0.C;
+    const int r0 = by * RG, col0 = bx * CS;
+    const int rn = min(RG, Cred - r0), cn = min(CS, ncol - col0);
+    if (rn > 0 && cn > 0) {
+        const DivU32 dk((unsigned)KK);
+        if (a0.mode == 0) {          // w[col][r][t]: per column a run of rn KK floats
+            const int run = rn * KK;
+            const DivU32 dr((unsigned)run);
+            for (int idx = threadIdx.x; idx < cn * run; idx += 256) {
+                unsigned col, rem, r, t;
+                dr.divmod((unsigned)idx, col, rem);
+                dk.divmod(rem, r, t);
+                lds[((int)r * CS + (int)col) * S + (int)t] = a0.w[((int64_t)(col0 + (int)col) * a0.C + r0) * KK + rem];
+            }
+        } else {                     // w[r][col][t]: per reduction channel a run of cn KK floats
+            const int run = cn * KK;
+            const DivU32 dr((unsigned)run);
+            for (int idx = threadIdx.x; idx < rn * run; idx += 256) {
+                unsigned r, rem, col, t;
+                dr.divmod((unsigned)idx, r, rem);
+                dk.divmod(rem, col, t);
+                lds[((int)r * CS + (int)col) * S + (int)t] = a0.w[((int64_t)(r0 + (int)r) * a0.C + col0) * KK + rem];
+            }
+        }
+    }
+    __syncthreads();
+    unsigned bits = 0u;
+    if (a0.fmt) bits = a0.wmax_single ? (unsigned)__builtin_amdgcn_readfirstlane((int)*a0.wmax) : absmax_read(a0.wmax);
+    const float sc = pow2f(f16_scale_exp(bits));
+    const int csh = CS == 64 ? 6 : (CS == 32 ? 5 : 4);
+    const int ng8 = RG / 8;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const PackArgs& a = batch.ph[ph];
+        const int T = a.TH * a.TW;
+        // work items (unit row of this block, column), columns fastest
+        const int nrow = ng8 * a.Tp;
+        for (int it = threadIdx.x; it < (nrow << csh); it += 256) {
+            const int cl = it & (CS - 1), row = it >> csh;
+            const int c8 = row / a.Tp, t = row - c8 * a.Tp;
+            const int col = col0 + cl;
+            const int u = (r0 / 8 + c8) * a.Tp + t;
+            if (col >= a.ld || u >= a.urows) continue;
+            float v[8];
+            const bool tap_ok = t < T && cl < cn;
+            int tapidx = 0;
+            if (tap_ok) {
+                const int th = t / a.TW, tw = t - th * a.TW;
+                tapidx = (a.kh0 + a.s * th) * a.KW + a.kw0 + a.s * tw;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (tap_ok && c8 * 8 + e < rn) ? lds[((c8 * 8 + e) * CS + cl) * S + tapidx] : 0.0f;
+            pack_win_emit(a, v, sc, (int64_t)u * a.ld + col);
+        }
+        if (by == gy - 1) {          // zero rows behind this block's last unit (padding groups of single-tap layers, the tail)
+            const int u0 = (r0 / 8 + ng8) * a.Tp;
+            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int it = threadIdx.x; it < ((a.urows - u0) << csh); it += 256) {
+                const int cl = it & (CS - 1), u = u0 + (it >> csh);
+                if (col0 + cl < a.ld) pack_win_emit(a, z, 1.0f, (int64_t)u * a.ld + col0 + cl);
+            }
+        }
+        if (a.fmt && !a.wmax_single && bx == 0 && by == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(a.out) = bits;
+    }
+}
+
 // One packing job = all phases of one panel; `kind` selects the body, (gx, gy) is its virtual grid.
 struct PackJob {
     PackBatch batch;
@@ -476,7 +419,11 @@ static PackJob make_pack_job(const PackBatch& b, int nphase) {
     PackJob j;
     j.batch = b; j.nphase = nphase; j.block_start = 0; j.pad = 0;
     const PackArgs& a0 = b.ph[0];
-    if (a0.mode == 0 && nphase == 1) {
+    if (a0.win) {
+        const int KK = a0.KH * a0.KW;
+        j.kind = 4; j.gx = (a0.ld + win_pack_cs(KK) - 1) / win_pack_cs(KK);
+        j.gy = ((a0.mode == 0 ? a0.C : a0.M) + win_pack_rg(KK) - 1) / win_pack_rg(KK);
+    } else if (a0.mode == 0 && nphase == 1) {
         j.kind = 0; j.gx = (a0.rows + 63) / 64; j.gy = (a0.ld + 63) / 64;
     } else if (a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS && a0.direct) {
         j.kind = 3; j.gx = (a0.ld + packd_cs(a0.KH * a0.KW) - 1) / packd_cs(a0.KH * a0.KW); j.gy = (a0.M + PACKD_MB - 1) / PACKD_MB;
@@ -498,6 +445,7 @@ __device__ __forceinline__ void pack_job_body(const PackJob& j, int local, float
     if (j.kind == 0) pack_transpose_body(j.batch.ph[0], bx, by, smem);
     else if (j.kind == 1) pack_adjoint_body(j.batch, j.nphase, bx, by, smem);
     else if (j.kind == 3) pack_adjoint_direct_body(j.batch, j.nphase, bx, by, smem);
+    else if (j.kind == 4) pack_win_body(j.batch, j.nphase, bx, by, j.gy, smem);
     else pack_generic_body(j.batch, bx, by, j.gx, smem);
 }
 
@@ -515,10 +463,32 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const PackJob job) {
 __device__ __forceinline__ void pack_clear_one(const PackJob& j, int ph) {
     if (ph < j.nphase && j.batch.ph[ph].fmt && !j.batch.ph[ph].direct) {
         const PackArgs& a = j.batch.ph[ph];
-        unsigned* hdr = reinterpret_cast<unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld));
+        unsigned* hdr = reinterpret_cast<unsigned*>(a.win ? a.out : a.out + panel_split_offset_dev(a.rows, a.ld));
         hdr[0] = 0u; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u;
     }
 }
+// window panels of fp16 pieces packed without the optimizer's absmax words: the largest weight magnitude goes into every phase's
+// header word first (the packing blocks read it from there).  blockIdx.y = job.
+__device__ __forceinline__ void win_absmax_body(const PackJob& j, int bx, int nbx) {
+    const PackArgs& a0 = j.batch.ph[0];
+    if (j.kind != 4 || !a0.fmt || !a0.wmax_single) return;
+    __shared__ float red[16];
+    const int64_t total = (int64_t)a0.M * a0.C * a0.KH * a0.KW;
+    float am = 0.0f;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nbx * 256) am = fmaxf(am, fabsf(a0.w[i]));
+    am = block_max(am, red);
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(am);
+        for (int ph = 0; ph < j.nphase; ++ph) {
+            unsigned* word = reinterpret_cast<unsigned*>(j.batch.ph[ph].out);
+            if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+#define WIN_ABSMAX_BLOCKS 64
+__global__ void __launch_bounds__(256) win_absmax_kernel(const PackJob job) { win_absmax_body(job, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) win_absmax_jobs_kernel(const PackJob* __restrict__ jobs) { win_absmax_body(jobs[blockIdx.y], blockIdx.x, gridDim.x); }
 __global__ void __launch_bounds__(64) pack_clear_kernel(const PackJob job) { if (threadIdx.x < 4) pack_clear_one(job, threadIdx.x); }
 __global__ void __launch_bounds__(64) pack_clear_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -543,223 +513,6 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restric
     pack_job_body(j, blockIdx.x - j.block_start, smem);
 }
 
-// ---------------------------------------------------------------------------------------------
-// implicit-GEMM gather kernel:
-//   out[b, m, oy, ox] = scale * sum_k wp[k][m] * in[b, :, qy*istride, qx*istride][koff[k]]  (+ bias[m])
-//   with (oy, ox) = (oy0 + qy*ostep, ox0 + qx*ostep); taps that fall outside the input contribute zero.
-// ---------------------------------------------------------------------------------------------
-struct IgPhase {
-    const float* wp;             // packed weights [rows][ld]
-    const int* koff;             // [rows]
-    const unsigned char* ktap;   // [rows]
-    const uint4* w3;             // [3][rows / 8][ld] chunks of 8 bf16, or [2][rows / 8][ld] chunks of 8 fp16 (see the panel layout)
-    const unsigned* a_absmax;    // fp16-piece panels: bit pattern of the largest weight magnitude of this phase
-    long long w3_plane;          // chunks per plane
-    int K, Kpad, ld, T;
-    int dmin;                    // the buffer descriptor of the gather starts dmin (<= 0) elements before the tensor
-    int oy0, ox0, QH, QW;
-    int TW, tw_magic;            // tap t = th*TW + tw, th = (t * tw_magic) >> 16  (exact for t < 32)
-    int dy0, dys, dx0, dxs;      // tap (th, tw) reads input (qy*istride + dy0 + dys*th, qx*istride + dx0 + dxs*tw)
-};
-
-struct IgParams {
-    const float* in;
-    float* out;
-    const float* bias;   // [M] or null
-    const float* scale;  // multiplies the contraction (1/sigma of spectral norm) or null; one value, or one per GROUP of
-    int scale_bg;        //   scale_bg consecutive batch elements (scale_bg = 0: a single value), scale_stride floats apart
-    int scale_stride;
-    long long in_bs, out_bs;
-    unsigned in_bytes;   // extent of the gathered tensor view in bytes (< 2^31): bound of the gather's buffer descriptor
-    int B, C, H, W;      // gathered tensor: C = reduction channels
-    int M, OH, OW;       // produced tensor
-    int istride, ostep, nphase;
-    int ksplit;          // > 1: K is split over blockIdx.z; partial tiles go to `slab`
-    float* slab;         //   combine == 0: dense [ksplit][B, M, OH, OW], summed by igemm_slab_reduce_kernel
-    long long slab_stride;
-    int precision;       // 0: fp32-faithful (three bf16 pieces per operand, six MFMAs per slice); 1: bf16 operands (one piece);
-                         // 2: fp32-faithful with two scaled fp16 pieces per operand, three MFMAs per slice (panel format 1)
-    const unsigned* b_absmax;   // precision 2: largest magnitude of the gathered tensor as AMAX_WORDS words of bit patterns (common.h)
-    // activated second output (1x1-map layers, skinny_rows_kernel only): act_out[n, j] = RootTanh(out[n, j]) with its own row
-    // stride, and - a style-chain link writing the NEXT link's input [latent | activation] (libs/block.py:119-125) - the
-    // lat_z latent columns copied in front of it: act_out - lat_z is then the start of that row
-    float* act_out;
-    long long act_bs;
-    const float* lat;
-    long long lat_bs;
-    int lat_z;
-    int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
-    unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
-    IgPhase ph[4];
-};
-
-// Shared epilogue of the implicit-GEMM kernels (both MFMA flavours have the same 32x32 accumulator layout).
-template <int WGM, int WGN, int TM, int TN>
-__device__ __forceinline__ void igemm_col_scales(const IgParams& p, const IgPhase& ph, float (&col_scale)[TN], int N, int n0,
-                                                 int wn, int lane) {
-    // 1/sigma of each of this lane's output columns (the batch may stack several forwards).  Loaded BEFORE the K loop:
-    // at its end it would be one more dependent memory round trip on the critical path of every block.
-    const int lcol = lane & 31;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nj = n0 + (wn * TN + j) * 32 + lcol;
-        const int nn = nj < N ? nj : 0;
-        const int b = nn / (ph.QH * ph.QW);
-        col_scale[j] = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
-    }
-}
-
-template <int WGM, int WGN, int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase& ph, f32x16 (&acc)[TM][TN],
-                                               const float (&col_scale)[TN], int N, int n0, int m0, int zsplit, int wm,
-                                               int wn, int lane, float* stage, bool split) {
-    const int lrow = lane >> 5, lcol = lane & 31;
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const long long plane = (long long)p.OH * p.OW;
-    // Small output planes (linears and the deep layers: 1x1 ... 4x4 maps): the lanes of an accumulator register hold 32
-    // different columns n = (b, pixel), whose addresses are a whole channel stack apart - 64 scattered 4-byte stores per
-    // instruction (measured: 5-11 us of a 10 us launch).  There the 32x32 tile goes through a wave-private LDS patch and
-    // is written out along (m, pixel), which is contiguous inside one batch element.
-    const int iplane = (int)plane;
-    if (stage != nullptr && p.nphase == 1 && p.ostep == 1 && iplane <= 16 && (iplane & (iplane - 1)) == 0 &&
-        ph.QH * ph.QW == iplane) {
-        const int lp = __ffs(iplane) - 1;
-        float* out_base = split ? p.slab + (long long)zsplit * p.slab_stride : p.out;
-        const long long obs = split ? (long long)p.M * plane : p.out_bs;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mt0 = m0 + (wm * TM + i) * 32;
-            float bias_v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mt0 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const bool use = p.bias != nullptr && !split && m < p.M;
-                const float* bp = use ? p.bias + m : p.in;
-                bias_v[r] = use ? *bp : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nt0 = n0 + (wn * TN + j) * 32;          // multiple of 32, hence of the plane size
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                    stage[lcol * 33 + ml] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                const int b0 = nt0 >> lp;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int flat = e * 64 + lane;
-                    const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
-                    const int ml = rem >> lp, pix = rem & (iplane - 1);
-                    const int nl = (bl << lp) + pix;
-                    const float v = stage[nl * 33 + ml];
-                    if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            }
-        }
-        return;
-    }
-    const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nj = n0 + (wn * TN + j) * 32 + lcol;
-        const int nn = nj < N ? nj : 0;
-        const int qhw = ph.QH * ph.QW;
-        const int b = nn / qhw, q = nn - b * qhw;
-        const int qy = q / ph.QW, qx = q - qy * ph.QW;
-        const long long pix = (long long)(ph.oy0 + qy * p.ostep) * p.OW + (ph.ox0 + qx * p.ostep);
-        const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
-                               : p.out + (long long)b * p.out_bs + pix;
-        optr[j] = nj < N ? o : nullptr;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float bias_v[16];          // this lane's 16 rows of the row tile: loaded together, branch-free
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            const bool use = p.bias != nullptr && !split && m < p.M;
-            const float* bp = use ? p.bias + m : p.in;          // always a valid address; value discarded when unused
-            bias_v[r] = use ? *bp : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float* o = const_cast<float*>(optr[j]);
-            if (o == nullptr) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
-            }
-        }
-    }
-}
-
-// XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private 4 MiB L2s), so
-// neighbouring tiles - which share a weight-panel slice (same m tile) or a gathered slice (same n tile) - would each
-// fetch it into a different L2.  Remap so that every XCD walks a contiguous chunk of the x-fastest tile order
-// (bijective for any grid size): the co-resident blocks of an XCD then share their operand slices through its L2.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
-    const int nx = gridDim.x, ny = gridDim.y;
-    const int nwg = nx * ny * (int)gridDim.z;
-    const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    bx = swz % nx;
-    const int t = swz / nx;
-    by = t % ny;
-    bz = t / ny;
-}
-
-// Per-thread state of the implicit-GEMM gather.  The gathered element of (column n, row k = (c, t)) sits at
-//   in + [b(n) in_bs + iy0(n) W + ix0(n)]  +  [c H W + dy(t) W + dx(t)]
-// = a lane part (fixed for the whole K loop) + a wave-uniform part (from the offset table): exactly the
-// voffset + soffset of a buffer load, whose descriptor also does the zero padding - a lane whose tap falls outside the
-// input passes an out-of-range voffset and gets 0 back without touching memory.  Per element that leaves three vector
-// instructions (mask bit -> voffset select) instead of the ~9 of 64-bit address arithmetic + two selects.
-struct GatherCol {
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned lane_off;   // bytes
-    unsigned outside;    // bit t: tap t reads OUTSIDE the input for this column (bit 31 is always set)
-};
-
-__device__ __forceinline__ GatherCol gather_setup(const IgParams& p, const IgPhase& ph, int n, int N) {
-    GatherCol g;
-    g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + ph.dmin), 0, (int)(p.in_bytes - 4 * ph.dmin), 0x00020000);
-    const bool n_ok = n < N;
-    const int nn = n_ok ? n : 0;
-    const int qhw = ph.QH * ph.QW;
-    const int b = nn / qhw, q = nn - b * qhw;
-    const int qy = q / ph.QW, qx = q - qy * ph.QW;
-    const int iy0 = qy * p.istride, ix0 = qx * p.istride;
-    g.lane_off = (unsigned)(4 * ((long long)b * p.in_bs + (long long)iy0 * p.W + ix0));
-    unsigned inside = 0;
-    if (n_ok) {
-        for (int t = 0; t < ph.T; ++t) {
-            const int th = (t * ph.tw_magic) >> 16, tw = t - th * ph.TW;
-            const bool ok = (unsigned)(iy0 + ph.dy0 + ph.dys * th) < (unsigned)p.H &&
-                            (unsigned)(ix0 + ph.dx0 + ph.dxs * tw) < (unsigned)p.W;
-            inside |= (ok ? 1u : 0u) << t;
-        }
-    }
-    g.outside = ~inside;
-    return g;
-}
-
-// soff: table entry of row k (bytes, wave-uniform); tap: its tap index (wave-uniform; 31 = never valid)
-__device__ __forceinline__ float gather_load(const GatherCol& g, int soff, unsigned tap) {
-    // two VALU ops per element: the tap's "outside" bit moves to bit 31 of the offset (lane_off < 2^31), which puts the
-    // access beyond num_records - the buffer load then returns 0 without touching memory (zero padding)
-    const unsigned vo = ((g.outside << (31u - tap)) & 0x80000000u) | g.lane_off;
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rsrc, (int)vo, soff, 0));
-}
-
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// NOTE (hipcc 7.2 / clang 22): __builtin_bit_cast applied DIRECTLY to an element of an ext_vector (`bit_cast(unsigned, v[k])`)
-// compiles to element 0 for every k.  Use __float_as_uint / __uint_as_float on vector elements, or copy to a scalar first.
 
 template <int WGM, int WGN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
@@ -1316,22 +1069,6 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     }
 }
 
-// Kernel-flavour switch for A/B timing and for the in-tree cross-check of the bf16 x 6 kernels against the fp32-MFMA ones
-// (LOCATE_DISABLE=bx6,wbx6,pointwise).  Compiled ONLY into the debug variant of the library (liblocate_hip_dbg.so,
-// -DLOCATE_DEBUG_KNOBS): the shipped liblocate_hip.so reads no environment variable, its dispatch depends on its arguments alone.
-#ifdef LOCATE_DEBUG_KNOBS
-static bool path_disabled(const char* name) {
-    static const char* env = getenv("LOCATE_DISABLE");
-    return env != nullptr && strstr(env, name) != nullptr;
-}
-static int knob_int(const char* name, int fallback) {
-    const char* v = getenv(name);
-    return v != nullptr ? atoi(v) : fallback;
-}
-#else
-static constexpr bool path_disabled(const char*) { return false; }
-static constexpr int knob_int(const char*, int fallback) { return fallback; }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Contractions on 1x1 maps (the style linears, the squeeze convs of the channel gates, the discriminator's head: a batch of
@@ -1532,7 +1269,13 @@ static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counter
     return sp;
 }
 
+void launch_slab_reduce(const IgParams& p, hipStream_t st) {
+    igemm_slab_reduce_kernel<<<stream_grid(p.slab_stride, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW,
+                                                                              p.out_bs, p.slab_stride, p.ksplit);
+}
+
 static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who) {
+    if (p.win) return launch_win_igemm(p, nmax, slab_ws, counters, st, who);
     if (skinny_ok(p)) {
         p.ksplit = 1;
         launch_skinny(p, st);
@@ -1609,6 +1352,12 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
 static int launch_pack(const PackBatch& b, int nphase, hipStream_t st, const char* who) {
     const PackJob j = make_pack_job(b, nphase);
     if (b.ph[0].fmt) pack_clear_kernel<<<1, 64, 0, st>>>(j);      // the absmax words the packing blocks fold their maxima into
+    if (b.ph[0].win) {                 // window panels: (largest magnitude into the headers,) one packing pass
+        if (b.ph[0].fmt) win_absmax_kernel<<<WIN_ABSMAX_BLOCKS, 256, 0, st>>>(j);
+        pack_job_kernel<<<j.gx * j.gy, 256, 0, st>>>(j);
+        LOCATE_LAUNCH_CHECK(who);
+        return LOCATE_OK;
+    }
     pack_job_kernel<<<j.gx * j.gy, 256, 0, st>>>(j);
     LOCATE_LAUNCH_CHECK(who);
     int64_t big = 1;
@@ -1633,6 +1382,7 @@ static ConvGeom make_geom(const int* g) {
 
 // geom = {B, C, H, W, M, KH, KW, stride, pad_h, pad_w, OH, OW} of the regular convolution R
 static size_t slab_floats(const IgParams& p, int nmax) {
+    if (p.win) return win_slab_floats(p, nmax);
     if (skinny_ok(p)) return 0;
     // the caller may or may not pass counters: room for whichever form the launch then takes
     const size_t a = igemm_split_plan(p, nmax, false).slab_floats, b = igemm_split_plan(p, nmax, true).slab_floats;
@@ -1698,12 +1448,126 @@ static void phase_finish(IgPhase& ph, const PackArgs& pa, float* panel_base) {
     ph.dy0 = pa.dy0; ph.dys = pa.dys; ph.dx0 = pa.dx0; ph.dxs = pa.dxs;
 }
 
+// Window form of a planned contraction (convwin.hip): turns the phase table conv_plan built into the window kernels' - panel
+// layout in unit order, tile structure, LDS window geometry, per-tap slot displacements - or returns false when this geometry
+// has none (the caller then keeps the gather kernels).  What the window kernels need:
+//   * >= 16 reduction channels, a multiple of 8; an even map width and even plane size (8-byte loads of pixel pairs; a power of
+//     two for stride-2 gathers);
+//   * column tiles (128 or 256 wide) that are whole rows of one image (BN % QW == 0) or whole images (BN % (QH QW) == 0), in every phase;
+//   * every phase with more than one tap, or a single phase with one tap (then the map is treated as flat pixel runs);
+//   * operand images that fit the LDS budget below.
+// The caller's alignment conditions on the tensor itself (base address, batch stride) are checked at launch.
+#define WIN_LDS_BUDGET (128 * 1024)
+static bool win_finish(IgParams& p, PackBatch& batch, int fmt, float* panel, size_t* off_out) {
+    if (path_disabled("win") || p.nphase < 1 || p.C < 16 || (p.C & 7)) return false;
+    bool any1 = false;
+    for (int i = 0; i < p.nphase; ++i) {
+        if (p.ph[i].T < 1) return false;
+        any1 = any1 || p.ph[i].T == 1;
+    }
+    if (any1 && (p.nphase > 1 || p.istride != 1 || p.ostep != 1 || p.ph[0].dy0 != 0 || p.ph[0].dx0 != 0 || p.H != p.OH || p.W != p.OW)) return false;
+    if (any1) {
+        // single tap: the map is a flat run of pixels; re-shape it into rows of min(HW, tile width) pixels
+        const long long HW = (long long)p.H * p.W;
+        if (HW < 2 || (HW & (HW - 1)) != 0) return false;          // powers of two only (every map of the model is)
+        int bn1 = 128;
+        if (knob_int("LOCATE_WIN_BM", 0) > 0 && p.M % knob_int("LOCATE_WIN_BM", 0) == 0) bn1 = win_pick_bn(knob_int("LOCATE_WIN_BM", 0));
+        if (knob_int("LOCATE_WIN_BN", 0) > 0) bn1 = knob_int("LOCATE_WIN_BN", 0);
+        const int Wc = HW >= bn1 ? bn1 : (int)HW;
+        p.W = p.OW = Wc; p.H = p.OH = (int)(HW / Wc);
+        p.ph[0].QW = Wc; p.ph[0].QH = p.H;
+        p.ph[0].TW = 1; p.ph[0].tw_magic = 65536;
+    }
+    if ((p.W & 1) || (((long long)p.H * p.W) & 1)) return false;
+    int bm = win_pick_bm(p.M), bn = win_pick_bn(bm);
+    if (any1) {
+        // single-tap layers (plain GEMMs of a few GFLOP): 64 x 128 tiles while that gives every CU a block, else 32 x 128
+        // (measured: profiles/notes_r04_experiments.md)
+        const long long N1 = (long long)p.B * p.H * p.W;
+        bn = 128;
+        bm = ((N1 + 127) / 128) * ((p.M + 63) / 64) >= 256 ? 64 : 32;
+    }
+    {   // (debug library: force a tile - LOCATE_WIN_BM rows, LOCATE_WIN_BN columns)
+        const int fbm = knob_int("LOCATE_WIN_BM", 0), fbn = knob_int("LOCATE_WIN_BN", 0);
+        if (fbm > 0 && p.M % fbm == 0) { bm = fbm; bn = win_pick_bn(bm); }
+        if (fbn > 0) bn = fbn;
+    }
+    const int C8G = (p.C + 7) / 8;
+    int X[4], nx = 0;
+    for (int i = 0; i < p.nphase; ++i) X[nx++] = any1 ? C8G : p.ph[i].T;
+    const int SL = win_pick_sl(X, nx), U = 2 * SL;
+    const int NP = fmt ? 2 : 3;
+    int slotsp = 0, bpt = 1;
+    size_t off = 0;
+    for (int i = 0; i < p.nphase; ++i) {
+        IgPhase& ph = p.ph[i];
+        PackArgs& pa = batch.ph[i];
+        const int QHW = ph.QH * ph.QW;
+        if (QHW >= bn) {
+            if (QHW % bn != 0 || bn % ph.QW != 0) return false;
+            ph.win_NI = 1; ph.win_TR = bn / ph.QW;
+        } else {
+            if (bn % QHW != 0) return false;
+            ph.win_NI = bn / QHW; ph.win_TR = ph.QH;
+        }
+        const int T = ph.T, TH = T / ph.TW;
+        if (TH * ph.TW != T || T > 25) return false;
+        const int dyA = ph.dy0, dyB = ph.dy0 + ph.dys * (TH - 1);
+        const int dymin = dyA < dyB ? dyA : dyB, dymax = dyA < dyB ? dyB : dyA;
+        int WR = (ph.win_TR - 1) * p.istride + (dymax - dymin) + 1;
+        if (WR > p.H) WR = p.H;
+        ph.win_WR = WR;
+        fastdiv_make((unsigned)(WR * p.W), &ph.win_wrw_mul, &ph.win_wrw_s1, &ph.win_wrw_s2);
+        ph.win_Tp = T == 1 ? 1 : round_up(T, U);
+        ph.win_NG = T == 1 ? 1 : ph.win_Tp / U;
+        const int slots = ph.win_NI * WR * p.W;
+        if (slots + 2 > slotsp) slotsp = slots + 2;          // + the trash slot (masked items' chunks) and the zero slot (taps outside the input)
+        // the loader's capacity: at most two items (pixel pairs x 8 channels) per thread and stage
+        const long long items = (long long)(T == 1 ? U : 1) * (slots / 2);
+        if (items > 2ll * 256 * ph.win_NG) return false;
+        if (items > 256ll * ph.win_NG) bpt = 2;
+        for (int t = 0; t < 32; ++t) {
+            int c = 0;
+            if (t < T) {
+                const int th = t / ph.TW, tw = t - th * ph.TW;
+                const int dy = ph.dy0 + ph.dys * th, dx = ph.dx0 + ph.dxs * tw;
+                c = dy * p.W + (p.istride == 2 ? (dx & 1) * (p.W / 2) + (dx >> 1) : dx);
+            }
+            ph.tapc[t] = c;
+        }
+        const int C8Gp = T == 1 ? round_up(C8G, U) : C8G;
+        pa.win = 1; pa.Tp = ph.win_Tp; pa.urows = C8Gp * ph.win_Tp + WIN_TAIL_UNITS;
+        pa.out = panel ? panel + off : nullptr;
+        // the panel is header + planes: the K-major fp32 rows, offset tables and their pointers do not exist
+        ph.wp = nullptr; ph.koff = nullptr; ph.ktap = nullptr;
+        ph.a_absmax = (fmt && pa.out) ? reinterpret_cast<const unsigned*>(pa.out) : nullptr;
+        ph.w3 = pa.out ? reinterpret_cast<const uint4*>(pa.out + PANEL_HDR) : nullptr;
+        ph.w3_plane = (long long)pa.urows * pa.ld;
+        ph.Kpad = C8Gp * ph.win_Tp * 8;
+        // non-direct packing reads its scale from the panel's own header (win_absmax_jobs_kernel)
+        pa.wmax = (fmt && pa.out) ? reinterpret_cast<const unsigned*>(pa.out) : nullptr;
+        pa.wmax_single = 1;
+        off += win_panel_floats(pa.urows, pa.ld, fmt);
+    }
+    if (p.istride == 2 && (p.W & (p.W - 1))) return false;          // (the parity de-interleave masks with W - 1)
+    int ngm = 1;
+    for (int i = 0; i < p.nphase; ++i) ngm = p.ph[i].win_NG > ngm ? p.ph[i].win_NG : ngm;
+    const size_t lds = ((size_t)2 * NP * U * bm + (size_t)2 * NP * (any1 ? U : 1) * slotsp) * 16 + (size_t)ngm * bpt * 256 * 8;
+    if (lds > WIN_LDS_BUDGET) return false;
+    if (any1)
+        for (int t = 0; t < 32; ++t) p.ph[0].tapc[t] = t < U ? t * slotsp : 0;
+    p.win = 1; p.win_U = U; p.win_slotsp = slotsp; p.win_bm = bm; p.win_bn = bn;
+    *off_out = off;
+    return true;
+}
+
 // Fills the phase table of R (adjoint = 0) or of its data adjoint (adjoint = 1: one phase per sub-pixel).
 // `panel` is the packed-weight buffer (may be null when only sizes are wanted); with `pack` the packing kernels
 // are launched.  Returns the panel size in floats and the largest per-phase N.
 static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* panel, IgParams& p, int* nmax_out,
                      size_t* panel_floats_out, bool pack, hipStream_t st, PackBatch* batch_out = nullptr) {
-    // adjoint_fmt: bit 0 = direction (0: R, 1: its data adjoint), bit 1 = panel format (0: bf16 planes, 1: fp16-piece planes)
+    // adjoint_fmt: bit 0 = direction (0: R, 1: its data adjoint), bit 1 = panel format (0: bf16 planes, 1: fp16-piece planes),
+    // bit 2 = window panel (chunk rows in unit order for the LDS-window kernels of convwin.hip; win_finish below)
     const int adjoint = adjoint_fmt & 1, fmt = (adjoint_fmt >> 1) & 1;
     size_t off = 0;
     int nmax = 0;
@@ -1722,6 +1586,7 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
         pa.gHW = g.H * g.W; pa.gW = g.W; pa.dy0 = pa.kh0 - g.pad_h; pa.dys = 1; pa.dx0 = pa.kw0 - g.pad_w; pa.dxs = 1;
         pa.dmin = tap_dmin(pa);
         pa.fmt = fmt; pa.wmax = nullptr; pa.direct = 0; pa.keep_f32 = 1;
+        pa.win = 0; pa.Tp = 0; pa.urows = 0; pa.wmax_single = 0;
         batch.ph[0] = pa;
         IgPhase& ph = p.ph[0];
         phase_finish(ph, pa, panel);
@@ -1756,6 +1621,7 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
                 pa.gHW = g.OH * g.OW; pa.gW = g.OW; pa.dy0 = dy0; pa.dys = -1; pa.dx0 = dx0; pa.dxs = -1;
                 pa.dmin = tap_dmin(pa);
                 pa.fmt = fmt; pa.wmax = nullptr; pa.direct = 0; pa.keep_f32 = 1;
+                pa.win = 0; pa.Tp = 0; pa.urows = 0; pa.wmax_single = 0;
                 batch.ph[p.nphase - 1] = pa;
                 phase_finish(ph, pa, pa.out);
                 ph.T = TH * TW;
@@ -1764,6 +1630,10 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
                 const int nph = g.B * QH * QW;
                 if (nph > nmax) nmax = nph;
             }
+    }
+    p.win = 0;
+    if (adjoint_fmt & 4) {
+        LOCATE_REQUIRE(win_finish(p, batch, fmt, panel, &off), "conv: this geometry has no window form (ask locate_conv_win_ok first)");
     }
     if (nmax_out) *nmax_out = nmax;
     if (panel_floats_out) *panel_floats_out = off;
@@ -1811,7 +1681,14 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
     PackBatch batch;
     if (int e = conv_plan(g, adjoint, w, panel, p, nullptr, nullptr, false, nullptr, &batch)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "locate_conv_pack_job: empty panel");
-    if (direct && (weight_absmax || !(adjoint & 2))) {
+    if (batch.ph[0].win) {
+        // window panels are always packed in one pass; "direct" = their scale is at hand (bf16 pieces need none, fp16 pieces take
+        // the optimizer's absmax words) - otherwise the launch runs the absmax pre-pass into the panel headers first
+        for (int i = 0; i < p.nphase; ++i) {
+            if (weight_absmax && (adjoint & 2)) { batch.ph[i].wmax = static_cast<const unsigned*>(weight_absmax); batch.ph[i].wmax_single = 0; }
+            batch.ph[i].direct = (weight_absmax || !(adjoint & 2)) ? 1 : 0;
+        }
+    } else if (direct && (weight_absmax || !(adjoint & 2))) {
         const PackArgs& a0 = batch.ph[0];
         const bool transpose = a0.mode == 0 && p.nphase == 1;
         const bool adj = a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS;
@@ -1836,10 +1713,15 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
 
 // any_f16: some job is a TWO-PASS fp16-piece panel (its absmax header is cleared first); any_two_pass: some job is in the
 // two-pass form at all (the split launch is needed) - both 0 when every job was built in the direct form: one launch.
-LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int any_two_pass, void* stream) {
+// passes: bit 0 = some gather-kernel panel is in the two-pass form (split launch), bit 1 = some WINDOW panel of fp16 pieces has no
+// absmax words (absmax pre-pass into the panel headers).
+LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_blocks, int any_f16, int passes, void* stream) {
     LOCATE_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "locate_conv_pack_panels: bad arguments");
+    const int any_two_pass = passes & 1;
     if (any_f16)        // fp16-piece panels: zero the absmax words the packing blocks fold their maxima into
         pack_clear_jobs_kernel<<<(4 * n_jobs + 63) / 64, 64, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
+    if (passes & 2)
+        win_absmax_jobs_kernel<<<dim3(WIN_ABSMAX_BLOCKS, n_jobs), 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs));
     pack_jobs_kernel<<<total_blocks, 256, 0, as_stream(stream)>>>(static_cast<const PackJob*>(jobs), n_jobs);
     LOCATE_LAUNCH_CHECK("locate_conv_pack_panels");
     if (any_two_pass) {
@@ -1849,6 +1731,13 @@ LOCATE_API int locate_conv_pack_panels(const void* jobs, int n_jobs, int total_b
     return LOCATE_OK;
 }
 // whether a job built by locate_conv_pack_job took the direct form (then it needs neither the clearing nor the split launch)
+// 1 for a window panel's job (its non-direct form needs pass bit 1 of locate_conv_pack_panels, never the split launch)
+LOCATE_API int locate_conv_pack_job_is_window(const void* job) {
+    if (!job) return 0;
+    PackJob j;
+    memcpy(&j, job, sizeof(j));
+    return j.kind == 4;
+}
 LOCATE_API int locate_conv_pack_job_is_direct(const void* job) {
     if (!job) return 0;
     PackJob j;
@@ -1868,6 +1757,8 @@ struct LocateActEpilogue {
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
                      int scale_bg, int scale_stride, const float* bias, float* out, int64_t out_bs, float* ws, unsigned* counters,
                      int precision, const unsigned* in_absmax, hipStream_t st, const char* who, const LocateActEpilogue* epi = nullptr) {
+    const int win = (precision >> 4) & 1;          // bit 4: the panel is a window panel (locate_conv_win_ok)
+    precision &= 15;
     LOCATE_REQUIRE(precision >= 0 && precision <= 2, "%s: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)", who);
     LOCATE_REQUIRE(precision != 2 || in_absmax, "%s: precision 2 needs the gathered tensor's absmax word", who);
     IgParams p;
@@ -1875,8 +1766,10 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
     p.b_absmax = in_absmax;
     p.act_out = nullptr; p.act_bs = 0; p.lat = nullptr; p.lat_bs = 0; p.lat_z = 0;
     int nmax = 0;
-    if (int e = conv_plan(g, adjoint | (precision == 2 ? 2 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
+    if (int e = conv_plan(g, (adjoint & 1) | (win ? 4 : 0) | (precision == 2 ? 2 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
+    LOCATE_REQUIRE(!win || ((in_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0), "%s: the window form loads pixel pairs: 8-byte aligned tensor, even batch stride", who);
+    LOCATE_REQUIRE(!win || !(epi && epi->act_out), "%s: no activated second output in the window form", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
     p.scale_bg = scale_bg; p.scale_stride = scale_stride;
     {
@@ -1899,8 +1792,47 @@ static size_t igemm_ws_bytes(const int* geom, int adjoint) {
     IgParams p;
     p.precision = 0;
     int nmax = 0;
-    conv_plan(make_geom(geom), adjoint, nullptr, nullptr, p, &nmax, nullptr, false, nullptr);
+    if (conv_plan(make_geom(geom), adjoint, nullptr, nullptr, p, &nmax, nullptr, false, nullptr)) return 0;
     return (p.nphase > 0 ? slab_floats(p, nmax) : 0) * sizeof(float);
+}
+
+// Whether this geometry and direction (bit 0 of adjoint_fmt; bit 1 = fp16-piece planes) has a WINDOW form (convwin.hip): the
+// caller then packs the panel with format bit 2 set (adjoint_fmt | 4, here and in locate_conv_panel_bytes / _pack_panel / _pack_job)
+// and passes adjoint-direction entry points the same panel as before; locate_conv_fwd / locate_conv_dgrad take the flag through
+// their `precision` argument's bit 4 (precision | 16).  x_bs / x: the gathered tensor's batch stride and address (pixel pairs are
+// loaded 8 bytes wide).  1x1 maps and the narrow streaming layers keep their own kernels: 0 for them.  Returns 1 where the window
+// form is also the faster one on MI355X (what the Python layer takes by default), 2 where it merely exists.
+LOCATE_API int locate_conv_win_ok(const int* geom, int adjoint_fmt, int64_t x_bs, const void* x) {
+    const ConvGeom g = make_geom(geom);
+    if (geom_check(g, "locate_conv_win_ok")) return 0;
+    if ((x_bs & 1) || (reinterpret_cast<uintptr_t>(x) & 7)) return 0;
+    IgParams p;
+    p.precision = 0;
+    int nmax = 0;
+    if (conv_plan(g, adjoint_fmt & 1, nullptr, nullptr, p, &nmax, nullptr, false, nullptr) || p.nphase < 1) return 0;
+    p.in = static_cast<const float*>(x); p.out = nullptr; p.in_bs = x_bs; p.out_bs = 2;
+    if (skinny_ok(p)) return 0;
+    {   // the narrow pointwise stream (geometry part of pointwise_ok)
+        const IgPhase& ph = p.ph[0];
+        if (p.nphase == 1 && ph.T == 1 && p.istride == 1 && p.ostep == 1 && p.H == p.OH && p.W == p.OW && ph.K <= 64 && p.M <= 64 &&
+            (long long)p.B * p.H * p.W >= 131072 && !path_disabled("pointwise")) return 0;
+    }
+    if (conv_plan(g, (adjoint_fmt & 3) | 4, nullptr, nullptr, p, &nmax, nullptr, false, nullptr) || !p.win) return 0;
+    // 1: the window form is the measured choice (profiles/notes_r04_experiments.md: the weight-streaming layers - a single tap over
+    // >= 384 reduction channels, the four 2x2-tap phases of a transposed 4x4 stride-2 conv over >= 512); 2: it exists and is
+    // correct, the gather kernels measured as fast or faster
+    bool taps4 = p.nphase == 4;
+    for (int i = 0; i < p.nphase; ++i) taps4 = taps4 && p.ph[i].T == 4;
+    const bool best = p.M >= 128 && ((p.nphase == 1 && p.ph[0].T == 1 && p.C >= 384) || (taps4 && p.C >= 512));
+    return best ? 1 : 2;
+}
+// split-K workspace of the window form (0 when the launch already fills the chip)
+LOCATE_API size_t locate_conv_win_workspace_bytes(const int* geom, int adjoint_fmt) {
+    IgParams p;
+    p.precision = (adjoint_fmt & 2) ? 2 : 0;
+    int nmax = 0;
+    if (conv_plan(make_geom(geom), (adjoint_fmt & 3) | 4, nullptr, nullptr, p, &nmax, nullptr, false, nullptr) || !p.win) return 0;
+    return win_slab_floats(p, nmax) * sizeof(float);
 }
 
 // split-K slab space (0 when the launch already fills the chip)
@@ -1975,18 +1907,6 @@ struct WgParams {
     const unsigned* g_absmax;
 };
 
-// n / d for 0 <= n < 2^31 as t = mulhi(n, mul); (t + ((n - t) >> s1)) >> s2   (Granlund-Montgomery)
-__device__ __forceinline__ int fastdiv(int n, unsigned mul, int s1, int s2) {
-    const unsigned t = __umulhi((unsigned)n, mul);
-    return (int)((t + (((unsigned)n - t) >> s1)) >> s2);
-}
-static void fastdiv_make(unsigned d, unsigned* mul, int* s1, int* s2) {
-    if (d <= 1) { *mul = 0; *s1 = 0; *s2 = 0; return; }
-    int l = 0;
-    while ((1ull << l) < d) ++l;
-    *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    *s1 = 1; *s2 = l - 1;
-}
 
 // Shared epilogue of the weight-gradient kernels.
 template <int WGM, int WGN, int TM, int TN>

@@ -1108,7 +1108,8 @@ def refresh_panels(params):
                                          ctypes.byref(nb), direct, wm[i]), "locate_conv_pack_job")
             start += nb.value
             if not L.locate_conv_pack_job_is_direct(ctypes.addressof(host) + i * rec):
-                two_pass = 1
+                # pass bits of locate_conv_pack_panels: 1 = split launch (gather-kernel panels), 2 = absmax pre-pass (window panels)
+                two_pass |= 2 if L.locate_conv_pack_job_is_window(ctypes.addressof(host) + i * rec) else 1
                 two_pass_f16 |= int(bool(key[0] & 2))
         table = torch.frombuffer(host, dtype=torch.uint8).clone().to(stale[0][0].device)
         plan = (table, len(stale), start, two_pass_f16, two_pass)
@@ -1206,6 +1207,35 @@ def _f16_ok(spec, geom, precision, *amax):
     return precision == 0 and spec.mode == "dense" and all(a is not None for a in amax) and _flops(geom) >= F16_MIN_FLOPS
 
 
+# LOCATE_WINDOW: "0" = gather kernels everywhere, "all" = the window kernels wherever the geometry has the form (tests, A/B runs),
+# default = where locate_conv_win_ok says they are the measured choice
+WIN_MODE = {"0": 0, "all": 2}.get(os.environ.get("LOCATE_WINDOW", "1"), 1)
+WIN_CALLS = [0]                                                 # launches that took the window form (tests check the path is live)
+_WIN_CACHE = {}
+
+
+def _win_ok(geom, garr, adjfmt, x):
+    """Whether this contraction takes the window form (locate_conv_win_ok: 1 = recommended, 2 = available), remembered per
+    geometry / direction / alignment."""
+    if not WIN_MODE:
+        return False
+    key = (tuple(geom), adjfmt, _bs(x) & 1, x.data_ptr() & 7)
+    hit = _WIN_CACHE.get(key)
+    if hit is None:
+        hit = lib().locate_conv_win_ok(garr, adjfmt, _bs(x), _p(x))
+        _WIN_CACHE[key] = hit
+    return hit == 1 or (hit == 2 and WIN_MODE == 2)
+
+
+def _win_ws_bytes(geom, garr, adjfmt):
+    key = (tuple(geom), adjfmt, "ws")
+    hit = _WIN_CACHE.get(key)
+    if hit is None:
+        hit = lib().locate_conv_win_workspace_bytes(garr, adjfmt)
+        _WIN_CACHE[key] = hit
+    return hit
+
+
 def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, precision=0, amax=None, epilogue=None):
     """y = R(x) (forward_of_r) or R^T(x), times 1/sigma, plus bias - dispatched on the layer's grouping mode.
     amax: x's largest-magnitude word, if its producer left one (fp16-piece form, panel format bit 2).
@@ -1218,13 +1248,23 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
         prec, fmt, am = (2, 2, amax) if f16 else (precision, 0, None)
         if f16:
             F16_CALLS["fwd" if forward_of_r == (spec.kind == "conv") else "dgrad"] += 1
+        adj = 0 if forward_of_r else 1
+        # the window form (csrc/convwin.hip): the gathered operand staged in LDS once for all taps - where the geometry has it
+        win = epilogue is None and _win_ok(geom, garr, adj | fmt, x)
+        if win:
+            fmt |= 4
+            prec |= 16
+            WIN_CALLS[0] += 1
+            ws = _ws(_win_ws_bytes(geom, garr, adj | (fmt & 2)), x.device)
         if forward_of_r:
-            ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
+            if not win:
+                ws = _ws(L.locate_conv_fwd_workspace_bytes(garr), x.device)
             check(L.locate_conv_fwd(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 0 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
                                     _bs(y), _p(ws), _p(_counters(owner, 0)), prec, _p(am),
                                     ctypes.addressof(epilogue) if epilogue is not None else None, st), "locate_conv_fwd")
         else:
-            ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
+            if not win:
+                ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
             check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
                                       _bs(y), _p(ws), _p(_counters(owner, 1)), prec, _p(am), st), "locate_conv_dgrad")
         return y

@@ -382,6 +382,109 @@ def test_conv_fp16_pieces_vs_cpu(kind, cin, cout, k, s, p, B, H, W, monkeypatch)
     assert_close(mod.module.weight_u.cpu(), P["module.weight_u"], 1e-5, "u")
 
 
+# Window form of the contractions (csrc/convwin.hip): geometries whose 128- / 256-column tiles are whole rows or whole images.
+# kind, Cin, Cout, k, stride, pad, B, H, W - every tile shape (192 / 128 rows x 128 columns, 96 / 64 / 32 rows x 256, the 64 / 32 x 128
+# tiles of single-tap layers), one and two slices per stage, multi-image and multi-row windows, stride-2 gathers (parity
+# de-interleave), partial last tiles, split-K with the in-launch combine
+WINDOW_CASES = [
+    ("convT", 64, 64, 4, 2, 1, 16, 4, 4),       # 2x2-tap phases, eight images per tile, 64 x 256 tiles
+    ("convT", 192, 192, 4, 2, 1, 4, 16, 16),    # tall 192 x 128 tiles, eight rows per tile (one halo row)
+    ("convT", 128, 96, 4, 2, 1, 3, 8, 8),       # 96 x 256 tiles (adjoint) / 128 x 128 (regular), a partial last tile
+    ("conv", 48, 48, 3, 1, 1, 2, 64, 64),       # the generator's 3x3 head: nine taps (ten units, one slice per stage), 64 x 256
+    ("conv", 32, 32, 5, 2, 2, 6, 32, 32),       # 5x5 stride 2: 25 taps, de-interleaved window columns, 32 x 256 tiles
+    ("conv", 64, 64, 5, 2, 2, 24, 8, 8),        # ... on small maps: 16 images per tile, windows loaded in parts from the item table
+    ("conv", 128, 128, 5, 2, 2, 40, 4, 4),      # ... 2x2 outputs: 64 images per tile, a partial last tile
+    ("conv", 256, 128, 1, 1, 0, 8, 16, 16),     # single tap: 64 x 128 / 32 x 128 tiles, four channel groups per stage
+    ("convT", 384, 192, 1, 1, 0, 4, 8, 8),      # transposed single tap, split-K (few tiles)
+    ("conv", 96, 160, 1, 1, 0, 3, 2, 64),       # single tap on a 2 x 64 map (flat pixel runs), ragged M
+    ("conv", 48, 48, 1, 1, 0, 5, 2, 2),         # 4-pixel maps: 32 images per tile, partial tile
+]
+
+
+@pytest.mark.parametrize("pieces", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,B,H,W", WINDOW_CASES)
+def test_conv_window_form_vs_cpu(kind, cin, cout, k, s, p, B, H, W, pieces, monkeypatch):
+    """Forward and input gradient through the window kernels (forced wherever the geometry has the form), weight gradient through
+    its own kernels, against ATen CPU convs through the SpectralNorm module - at the bounds of the gather kernels' test above, in
+    both fp32-faithful piece forms."""
+    from locate_amd import SpectralNorm, ops
+    from oracle import locate_oracle as O
+    monkeypatch.setattr(ops, "WIN_MODE", 2)
+    monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0)
+    ops._WIN_CACHE.clear()
+    torch.manual_seed(cin * 1000 + cout + k)
+    nn = torch.nn
+    inner = (nn.Conv2d if kind == "conv" else nn.ConvTranspose2d)(cin, cout, k, stride=s, padding=p, bias=False)
+    mod = SpectralNorm(inner)
+    sd = {kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(B, cin, H, W) * 3.0
+    P = O.make_params(sd)
+    xr = x.clone().requires_grad_(True)
+    w = O.sn_weight(P, "module.")
+    yr = F.conv2d(xr, w, None, s, p) if kind == "conv" else F.conv_transpose2d(xr, w, None, s, p)
+    g = torch.randn_like(yr) * (1e-4 if pieces == "f16x2" else 1.0)
+    yr.backward(g)
+    mod = mod.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    gg = g.to(dev())
+    if pieces == "f16x2":
+        xg, gg = ops.tag_amax(xg), ops.tag_amax(gg)
+    # which directions have the form in this piece format (three-piece windows of the largest cases exceed the LDS budget)
+    spec = ops.ConvSpec(kind, k, k, s, p, p)
+    geom, _ = spec.geometry(tuple(x.shape), (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k))
+    fmt = 2 if pieces == "f16x2" else 0
+    expect = sum(int(ops.lib().locate_conv_win_ok(ops._geom(geom), adj | fmt, 2, 16) > 0) for adj in (0, 1))
+    assert expect >= 1
+    before = ops.WIN_CALLS[0]
+    yg = mod(xg)
+    yg.backward(gg)
+    assert ops.WIN_CALLS[0] == before + expect, "every direction that has the window form took it"
+    assert_close(yg.cpu(), yr, 2e-5, "y")
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
+    assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
+    ops._WIN_CACHE.clear()
+
+
+def test_conv_window_form_stacked_calls_and_repack(monkeypatch):
+    """The window form under the step's own conditions: three stacked calls with their own 1/sigma per batch third (the epilogue's
+    group scales), a bias, an output written into a channel slice, and the panel re-packed after the weights changed (the batched
+    re-packing with and without the optimizer's absmax words) - each against the gather kernels on the same operands."""
+    from locate_amd import ops
+    L = ops.lib()
+    torch.manual_seed(5)
+    B, C, M, H = 24, 64, 48, 8
+    spec = ops.ConvSpec("conv", 5, 5, 2, 2, 2)
+    x = ops.tag_amax((torch.randn(B, C, H, H) * 2).to(dev()))
+    w = (torch.randn(M, C, 5, 5) * 0.05).to(dev()).requires_grad_(True)
+    bias = torch.randn(M).to(dev())
+    sigma = torch.tensor([[2.0, 0.5], [4.0, 0.25], [0.5, 2.0]], device=dev())
+    geom, out_shape = spec.geometry(tuple(x.shape), tuple(w.shape))
+    garr = ops._geom(geom)
+
+    def run(mode):
+        monkeypatch.setattr(ops, "WIN_MODE", mode)
+        ops._WIN_CACHE.clear()
+        buf = torch.zeros(B, M + 8, out_shape[2], out_shape[3], device=dev())
+        y = ops._conv_apply(x, w.detach(), w, spec, geom, garr, sigma, bias, out_shape, 0, ops._amax_of(x), buf[:, 8:])
+        return y.clone()
+
+    monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0)
+    before = ops.WIN_CALLS[0]
+    y_win = run(2)
+    assert ops.WIN_CALLS[0] == before + 1
+    y_gather = run(0)
+    assert_close(y_win.cpu(), y_gather.cpu(), 2e-6, "stacked window vs gather")
+    # the weights change (as after an optimizer step): both panels are stale and re-packed in one batched launch
+    with torch.no_grad():
+        w.mul_(1.5).add_(0.01)
+    ops.refresh_panels([w])
+    y_win2 = run(2)
+    y_gather2 = run(0)
+    assert_close(y_win2.cpu(), y_gather2.cpu(), 2e-6, "after re-packing")
+    assert float((y_win2 - y_win).abs().max()) > 1e-3
+    ops._WIN_CACHE.clear()
+
+
 GROUPED_CASES = [
     # kind, Cin, mult, k, stride, pad, B, H, W        (groups = Cin: the SEPARABLE switch, libs/conv.py:17)
     ("conv", 3, 1, 5, 2, 2, 4, 16, 16),        # D stem conv_0

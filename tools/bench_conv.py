@@ -29,6 +29,15 @@ SHAPES = [
     ("D.b3 conv5x5 256", "conv", 256, 256, 5, 2, 2, 4, 64),
     ("D.b4 conv5x5 512", "conv", 512, 512, 5, 2, 2, 2, 64),
     ("D.b3 conv1x1 256->512", "conv", 256, 512, 1, 1, 0, 2, 64),
+    ("D.b0 conv5x5 32 B192", "conv", 32, 32, 5, 2, 2, 32, 192),
+    ("D.b1 conv5x5 64 B192", "conv", 64, 64, 5, 2, 2, 16, 192),
+    ("D.b2 conv5x5 128 B192", "conv", 128, 128, 5, 2, 2, 8, 192),
+    ("D.b3 conv5x5 256 B192", "conv", 256, 256, 5, 2, 2, 4, 192),
+    ("G.b1 convT1x1 768->384", "convT", 768, 384, 1, 1, 0, 8, 64),
+    ("G.b2 convT1x1 384->192", "convT", 384, 192, 1, 1, 0, 16, 64),
+    ("G.sa conv1x1 192 (16x16)", "conv", 192, 192, 1, 1, 0, 16, 64),
+    ("D.b2 conv1x1 128 B192", "conv", 128, 128, 1, 1, 0, 8, 192),
+    ("D.b3 conv1x1 256 B192", "conv", 256, 256, 1, 1, 0, 4, 192),
 ]
 
 
@@ -59,6 +68,9 @@ CHECK = False          # --check: forward / input gradient against a float64 CPU
 ZEROS = False          # --zeros: all-zero operands (the chip holds a higher clock on them: separates clock-bound from issue-bound)
 
 
+WIN = False            # --win: the window form (csrc/convwin.hip) wherever the geometry has it
+
+
 def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, use_cnt=True, dev=None):
     """(ms forward, ms input gradient, ms weight gradient, algorithmic FLOPs, bytes forward) of one layer through the C ABI."""
     dev = dev or torch.device("cuda:0")
@@ -81,17 +93,21 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
     gw = torch.empty_like(w)
     one = torch.ones(1, device=dev)
     fmt = 2 if prec == 2 else 0          # panel format bit: fp16-piece planes
-    pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0 | fmt), 16), dtype=torch.uint8, device=dev)
-    pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1 | fmt), 16), dtype=torch.uint8, device=dev)
-    check(L.locate_conv_pack_panel(garr, 0 | fmt, w.data_ptr(), pan0.data_ptr(), S()))
-    check(L.locate_conv_pack_panel(garr, 1 | fmt, w.data_ptr(), pan1.data_ptr(), S()))
+    # window form per direction (R forward gathers x for a conv, gy for a transposed conv)
+    in0, in1 = (x, gy) if kind == "conv" else (gy, x)
+    win0 = 4 if (WIN and L.locate_conv_win_ok(garr, 0 | fmt, in0.stride(0), in0.data_ptr())) else 0
+    win1 = 4 if (WIN and L.locate_conv_win_ok(garr, 1 | fmt, in1.stride(0), in1.data_ptr())) else 0
+    pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0 | fmt | win0), 16), dtype=torch.uint8, device=dev)
+    pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1 | fmt | win1), 16), dtype=torch.uint8, device=dev)
+    check(L.locate_conv_pack_panel(garr, 0 | fmt | win0, w.data_ptr(), pan0.data_ptr(), S()))
+    check(L.locate_conv_pack_panel(garr, 1 | fmt | win1, w.data_ptr(), pan1.data_ptr(), S()))
     nw = L.locate_absmax_words()
     amax = torch.zeros(2 * nw, dtype=torch.int32, device=dev)       # absmax words of x and gy
     check(L.locate_absmax(x.data_ptr(), x.numel(), amax[0:].data_ptr(), S()))
     check(L.locate_absmax(gy.data_ptr(), gy.numel(), amax[nw:].data_ptr(), S()))
     slot = {x.data_ptr(): amax[0:].data_ptr(), gy.data_ptr(): amax[nw:].data_ptr()}
-    ws_f = torch.empty(max(L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
-    ws_d = torch.empty(max(L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+    ws_f = torch.empty(max(L.locate_conv_win_workspace_bytes(garr, 0 | fmt) if win0 else L.locate_conv_fwd_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
+    ws_d = torch.empty(max(L.locate_conv_win_workspace_bytes(garr, 1 | fmt) if win1 else L.locate_conv_dgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
     part = torch.empty(L.locate_conv_wgrad_partials(garr), dtype=torch.float64, device=dev)
     ws_w = torch.empty(max(L.locate_conv_wgrad_workspace_bytes(garr), 16), dtype=torch.uint8, device=dev)
     cnt_f = torch.zeros(L.locate_conv_counter_bytes(), dtype=torch.uint8, device=dev)
@@ -99,11 +115,11 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
 
     def r_fwd(inp, out):      # R forward
         check(L.locate_conv_fwd(garr, inp.data_ptr(), inp.stride(0), pan0.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, None, S()))
+                                out.stride(0), ws_f.data_ptr(), cnt_f.data_ptr() if use_cnt else None, prec | (16 if win0 else 0), slot[inp.data_ptr()] if prec == 2 else None, None, S()))
 
     def r_dgrad(inp, out):    # R data adjoint
         check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec, slot[inp.data_ptr()] if prec == 2 else None, S()))
+                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec | (16 if win1 else 0), slot[inp.data_ptr()] if prec == 2 else None, S()))
 
     if kind == "conv":
         fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
@@ -135,6 +151,8 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
         print("    max |err| / max |ref|:  fwd %.2e   dgrad %.2e   wgrad %.2e" % (
             float((y.double().cpu() - yr).abs().max() / yr.abs().max()), float((gx.double().cpu() - gr).abs().max() / gr.abs().max()),
             float((gw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())))
+    if WIN:
+        print("    window form: R forward %s, R adjoint %s" % (bool(win0), bool(win1)))
     ms = [time_it(f, reps) for f in (fwd, dgr, wgr)]
     nbytes = 4.0 * (x.numel() + y.numel()) + 6.0 * w.numel()      # activations once each + the three bf16 weight planes
     return ms, flops, nbytes
@@ -150,10 +168,12 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero operands")
     ap.add_argument("--f16", action="store_true", help="fp32-faithful with two scaled fp16 pieces per operand (precision 2)")
     ap.add_argument("--check", action="store_true", help="print the forward / input-gradient error against float64")
+    ap.add_argument("--win", action="store_true", help="the window form (csrc/convwin.hip) wherever the geometry has it")
     args = ap.parse_args()
-    global ZEROS, CHECK
+    global ZEROS, CHECK, WIN
     ZEROS = args.zeros
     CHECK = args.check
+    WIN = args.win
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
     shapes = SHAPES
