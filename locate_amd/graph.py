@@ -196,11 +196,11 @@ class GraphedTrainStep:
         else:
             self.graphs[0].replay()
             if red_d is not None:
-                red_d.reduce_now()
+                red_d.reduce_now(replay=True)
             self.graphs[1].replay()
             self.graphs[2].replay()
             if red_g is not None:
-                red_g.reduce_now()
+                red_g.reduce_now(replay=True)
             self.graphs[3].replay()
         # the replayed optimizer kernels changed the weights behind Python's back: bump the version counters so
         # that any later EAGER use (sampling, evaluation) re-packs its weight panels instead of trusting the cache

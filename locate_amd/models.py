@@ -179,6 +179,8 @@ class _NetBase(nn.Module):
         ops.AMAX.new_pass()          # this forward's largest-magnitude words come from a block of their own
         if stacked > 1 and not self.batched_spectral_norm:
             raise RuntimeError("a forward over stacked calls needs batched_spectral_norm = True")
+        if stacked > 4:
+            raise ValueError("at most 4 stacked calls per forward (the kernels' per-call 1/sigma groups and the deferred finalisers' records hold four)")
         if self.batched_spectral_norm:
             b = self._batch()
             if not b.layers:

@@ -62,12 +62,14 @@ class _AmaxArena:
     stand-alone use simply takes a new block whenever the current one is used up."""
     SLOTS = 32            # per block when nobody announced a step
     STEP_SLOTS = 160      # per training iteration (TrainStep): two generator and two discriminator forwards, three backward passes
+                          # - a first guess, raised to what an iteration actually took (end_step) before the next one starts
 
     def __init__(self):
         self.block, self.used, self.cap = None, 0, 0
         self.enabled = True
         self.words = None            # words per tensor (locate_absmax_words: producers spread their atomics over them)
         self._step = False
+        self._step_used = 0          # word sets the running iteration has taken in all (over every block)
 
     def new_pass(self):
         """A forward / backward pass begins: outside a training iteration it gets a block of its own."""
@@ -81,6 +83,7 @@ class _AmaxArena:
         if not self._step:
             self.block = None
             self._step = True
+            self._step_used = 0
         if device is not None and self.enabled and (self.block is None or self.block.device != device):
             if self.words is None:
                 self.words = lib().locate_absmax_words()
@@ -89,6 +92,10 @@ class _AmaxArena:
             self.used = 0
 
     def end_step(self):
+        """The iteration is over: the next one's block holds what this one took, with room to spare - a replayed (captured)
+        iteration can never need more than the eager iterations before it did."""
+        if self._step and self._step_used + 16 > self.STEP_SLOTS:
+            self.STEP_SLOTS = self._step_used + self._step_used // 4 + 16
         self._step = False
 
     def slot(self, device):
@@ -97,11 +104,22 @@ class _AmaxArena:
         if self.words is None:
             self.words = lib().locate_absmax_words()
         if self.block is None or self.used >= self.cap or self.block.device != device:
-            self.cap = self.STEP_SLOTS if self._step else self.SLOTS
+            overflow = self._step and self.block is not None and self.block.device == device
+            if overflow and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("hipGraph capture needs more largest-magnitude word sets (%d) than the iteration's block holds: "
+                                   "run one eager iteration of this configuration first (the block is sized from it)" % (self._step_used + 1))
+            self.cap = max(self.STEP_SLOTS, 2 * self.cap) if self._step else self.SLOTS
             self.block = torch.zeros(self.cap * self.words, dtype=torch.int32, device=device)
             self.used = 0
+            if overflow:
+                # a block created in the MIDDLE of an iteration: its zero-fill runs on this stream, while the word sets it hands
+                # out later may go to producers on other streams (the generator pass beside the discriminator's) - the fill must
+                # be complete before any of them can publish.  Eager iterations only, and only until end_step has sized the block.
+                torch.cuda.synchronize()
         s = self.block[self.used * self.words:(self.used + 1) * self.words]
         self.used += 1
+        if self._step:
+            self._step_used += 1
         return s
 
 
@@ -114,9 +132,17 @@ F16_MIN_FLOPS = 0.5e9
 F16_CALLS = {"fwd": 0, "dgrad": 0, "wgrad": 0}      # launches that took the fp16-piece form (tests check the path is live)
 
 
+def _tag(t, words):
+    """Attach a tensor's largest-magnitude words, stamped with the version of its data: an in-place change afterwards - autograd
+    summing a second consumer's gradient INTO this tensor - bumps the version counter and the stale words are ignored (the
+    contraction then takes the six-product form; a wrong maximum would mis-scale the fp16 pieces)."""
+    t._locate_amax = (words, t._version)
+    return t
+
+
 def _amax_of(t):
     """The largest-magnitude words of t, or None.  A full view of a tagged tensor (autograd's own reshape of a gradient on its
-    way through a view node) finds them on its base."""
+    way through a view node) finds them on its base (a view shares its base's version counter)."""
     if not AMAX.enabled:
         return None
     a = getattr(t, "_locate_amax", None)
@@ -124,7 +150,9 @@ def _amax_of(t):
         base = t._base
         if base is not None and base.numel() == t.numel() and base.data_ptr() == t.data_ptr():
             a = getattr(base, "_locate_amax", None)
-    return a
+    if a is None or a[1] != t._version:
+        return None
+    return a[0]
 
 
 def carry_amax(src, view):
@@ -132,8 +160,8 @@ def carry_amax(src, view):
     which Python attributes do not do by themselves."""
     if view is not src and view.numel() == src.numel() and view.data_ptr() == src.data_ptr():
         a = getattr(src, "_locate_amax", None)
-        if a is not None:
-            view._locate_amax = a
+        if a is not None and a[1] == src._version:
+            view._locate_amax = (a[0], view._version)
     return view
 
 
@@ -143,7 +171,7 @@ def tag_amax(t):
     slot = AMAX.slot(t.device)
     if slot is not None:
         check(lib().locate_absmax(_p(_c(t)), t.numel(), _p(slot), _stream()), "locate_absmax")
-        t._locate_amax = slot
+        _tag(t, slot)
     return t
 
 
@@ -167,10 +195,11 @@ class RootTanhFn(torch.autograd.Function):
         gx, acc = ctx.slot.claim(x) if ctx.slot is not None else (torch.empty_like(x), 0)
         # a fresh buffer of its own: its largest magnitude rides along for the contraction that consumes it (a shared fan-out
         # buffer does not get one - the other branch still adds into it)
-        amax = AMAX.slot(x.device) if ctx.slot is None else None
+        # (only where a contraction of F16_MIN_FLOPS could consume it: 4-d maps of some size, like the forward's rule)
+        amax = AMAX.slot(x.device) if (ctx.slot is None and x.dim() >= 3 and x.numel() >= (1 << 16)) else None
         check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), acc, _p(amax), _stream()), "locate_roottanh_bwd")
         if amax is not None:
-            gx._locate_amax = amax
+            _tag(gx, amax)
         return gx, None, None
 
 
@@ -231,7 +260,7 @@ def root_tanh(x):
     amax = AMAX.slot(x.device) if x.dim() >= 3 and x.numel() >= (1 << 16) else None
     y = RootTanhFn.apply(x, _slot_of(x) if x.is_contiguous() else None, amax)
     if amax is not None:
-        y._locate_amax = amax
+        _tag(y, amax)
     return y
 tanh = TanhFn.apply
 
@@ -525,6 +554,9 @@ class _Deferral:
 
 
 DEFAULT_RUNTIME = Runtime()     # layers used on their own (not inside a Generator / Discriminator)
+# stand-alone layers finish every parameter gradient inside their own backward node: torch.autograd.grad, tensor hooks and a
+# GradAllReducer used without TrainStep then see them (the networks' own runtimes defer to the end of the pass, TrainStep knows)
+DEFAULT_RUNTIME.defer_finalisers = False
 
 
 def stacked_calls(n):
@@ -733,7 +765,7 @@ def inplace_norm(x, scale, bias, with_act=False, runtime=None):
     amax = AMAX.slot(x.device) if x.numel() >= (1 << 16) else None
     out = InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None, amax, runtime)
     if amax is not None:
-        out._locate_amax = amax
+        _tag(out, amax)
     return out
 
 
@@ -791,7 +823,7 @@ class GateFn(torch.autograd.Function):
         check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), None if deferred else _p(dgamma),
                                 planes, hw, _p(ws), acc, _p(amax), _stream()), "locate_gate_bwd")
         if amax is not None:
-            da._locate_amax = amax
+            _tag(da, amax)
         if deferred:
             rt.queue_sum(ws, L.locate_gate_bwd_partials(planes, hw), dgamma)
             rt.late_grad(ctx.gamma_param, dgamma.view(ctx.gamma_param.shape))

@@ -114,7 +114,8 @@ class GradAllReducer:
         if reduce_op not in (None, "avg", "sum"):
             raise ValueError("reduce_op must be 'avg' or 'sum'")
         self._avg = (backend == "nccl") if reduce_op is None else reduce_op == "avg"
-        self._verified = set()     # (bucket, member tuple) combinations all ranks have been checked to agree on
+        self._replaying = False    # the running step is a hipGraph replay (begin_replay) - see _check_agreement
+        self._replays = 0
         self._copy_tables = {}     # (bucket, gradient / flat addresses) -> device tables of locate_multi_copy
         self.bucket_of = {}
         for b, idxs in enumerate(self.buckets):
@@ -145,6 +146,7 @@ class GradAllReducer:
         """Call right before backward()."""
         if not self.enabled:
             return
+        self._replaying = False
         # hooks are (re)registered lazily: a tensor can only carry one once it requires grad, and the
         # discriminator's u/v only start to after the first G-step (reference main.py:172)
         for i, p in enumerate(self.params):
@@ -213,14 +215,16 @@ class GradAllReducer:
 
     def _check_agreement(self, b, members):
         """Which parameters have a gradient is decided per rank (`grad is not None`); ranks that disagreed would exchange
-        buckets of different sizes - a hang or silent garbage.  The first time a bucket is sent with a given member list,
-        all ranks compare a digest of (bucket, members) with one tiny max-reduction of (h, -h): equal everywhere iff both
-        come back unchanged.  Every rank runs this check as the first collective of that bucket, so the check itself
-        always matches up; afterwards the combination is trusted."""
-        sig = (b, tuple(members))
-        if sig in self._verified:
+        buckets of different sizes - a hang or silent garbage.  Before a bucket goes out all ranks compare a digest of
+        (bucket, members) with one tiny max-reduction of (h, -h): equal everywhere iff both come back unchanged.
+        WHETHER the check runs is itself rank-invariant - it depends on the launch mode and a step count only, never on what
+        this rank has seen before (a rank that skipped the check while another ran it would pair the check's collective with
+        the bucket's): every eager (hook-driven) step checks every bucket; under hipGraph replay, where the member lists are
+        frozen into the captured graphs, the first two replays do and the rest do not (no host read in the replayed step)."""
+        if self._replaying and self._replays > 2:
             return
         import zlib
+        sig = (b, tuple(members))
         h = zlib.crc32(repr(sig).encode()) & 0x7fffffff
         dev = self.params[self.buckets[b][0]].device if self.buckets[b] else torch.device("cpu")
         t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
@@ -229,7 +233,6 @@ class GradAllReducer:
         if hi != h or -lo != h:
             raise RuntimeError("data-parallel ranks disagree on which parameters of bucket %d carry a gradient (this rank: %d "
                                "tensors): the replicas' backward passes differ" % (b, len(members)))
-        self._verified.add(sig)
 
     def _op(self):
         return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -239,6 +242,8 @@ class GradAllReducer:
         """Before replaying a captured backward: nothing is launched yet."""
         if not self.enabled:
             return
+        self._replaying = True
+        self._replays += 1
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._active = False
@@ -361,12 +366,16 @@ class GradAllReducer:
         self._t_comm, self._t_wait = [], []
         return total, exposed
 
-    def reduce_now(self):
+    def reduce_now(self, replay=False):
         """Non-overlapped form: average every existing .grad across the ranks right now, on the current stream.
         Used between two captured hipGraphs (backward graph -> all-reduce -> optimizer graph), where the hook-driven
-        overlap is not available; at config 2 the payload is 47 / 56 MB, ~1 ms of a 25 ms step over xGMI."""
+        overlap is not available; at config 2 the payload is 47 / 56 MB, ~1 ms of a 25 ms step over xGMI.
+        replay: the gradients come from a replayed graph (frozen member lists: see _check_agreement)."""
         if not self.enabled:
             return
+        self._replaying = bool(replay)
+        if replay:
+            self._replays += 1
         inv = None if self._avg else 1.0 / self.world
         for b, idxs in enumerate(self.buckets):
             members = [i for i in idxs if self.params[i].grad is not None]

@@ -485,6 +485,43 @@ def test_conv_window_form_stacked_calls_and_repack(monkeypatch):
     ops._WIN_CACHE.clear()
 
 
+def test_stale_largest_magnitude_tag_is_ignored(monkeypatch):
+    """A tensor's largest-magnitude words are only valid for the data they were taken from: when autograd sums a second consumer's
+    gradient INTO a tagged gradient (in place), the contraction that consumes the sum must not scale its fp16 pieces by the old
+    maximum (a sum 4x larger overflows the high piece to inf).  The tag carries the tensor's version; a stale one is ignored and
+    the contraction takes the six-product form.  Here: y = conv(x) feeds RootTanh (whose backward tags its gradient) AND a plain
+    torch op whose gradient is 30x larger."""
+    from locate_amd import SpectralNorm, ops
+    from oracle import locate_oracle as O
+    monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0)
+    t = ops.tag_amax(torch.randn(1 << 16, device=dev()))
+    assert ops._amax_of(t) is not None
+    t.add_(1.0)
+    assert ops._amax_of(t) is None, "an in-place change invalidates the tag"
+    torch.manual_seed(3)
+    inner = torch.nn.Conv2d(32, 48, 3, stride=1, padding=1, bias=False)
+    mod = SpectralNorm(inner)
+    sd = {kk: v.clone() for kk, v in mod.state_dict().items()}
+    x = torch.randn(8, 32, 32, 32)
+    P = O.make_params(sd)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, O.sn_weight(P, "module."), None, 1, 1)
+    g1, g2 = torch.randn_like(yr) * 1e-3, torch.randn_like(yr)
+    (O.RootTanhFn.apply(yr) * g1).sum().backward(retain_graph=True)
+    (yr * 30.0 * g2).sum().backward()
+    mod = mod.to(dev())
+    xg = ops.tag_amax(x.to(dev()).requires_grad_(True))
+    yg = mod(xg)
+    # RootTanh's branch is created last, so its backward runs first: its tagged gradient is the buffer the engine adds the other
+    # branch's (much larger) gradient into
+    big = yg * 30.0
+    small = ops.root_tanh(yg)
+    ((small * g1.to(dev())).sum() + (big * g2.to(dev())).sum()).backward()
+    assert torch.isfinite(xg.grad).all() and torch.isfinite(mod.module.weight_bar.grad).all()
+    assert_close(xg.grad.cpu(), xr.grad, 2e-5, "dx")
+    assert_close(mod.module.weight_bar.grad.cpu(), P["module.weight_bar"].grad, 5e-5, "dw")
+
+
 GROUPED_CASES = [
     # kind, Cin, mult, k, stride, pad, B, H, W        (groups = Cin: the SEPARABLE switch, libs/conv.py:17)
     ("conv", 3, 1, 5, 2, 2, 4, 16, 16),        # D stem conv_0
