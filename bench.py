@@ -29,9 +29,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--image-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "fp8"), default="fp32",
                     help="fp32 (headline): the reference's arithmetic.  bf16: contraction operands rounded to bf16, one MFMA per "
-                         "slice, fp32 accumulation and storage (BASELINE configs[1] as named; tolerances in tests/test_gpu_bf16.py)")
+                         "slice, fp32 accumulation and storage (BASELINE configs[1] as named; tolerances in tests/test_gpu_bf16.py).  "
+                         "fp8: operands as e4m3 on the fp8 matrix instruction (BASELINE configs[4]'s arithmetic; tests/test_gpu_fp8.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-only", action="store_true",
@@ -80,7 +81,7 @@ def _pmc_traffic(flops_by_stage):
         return None, "no PMC record (%s)" % type(e).__name__
 
 
-def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
+def conv_roofline(cfg, batch, dev, reps=10, bf16=False, fp8=False):
     """Dominant kernel: the implicit GEMM behind the generator's four C>=96 ConvTranspose 4x4 s2 stages (75 % of
     the step's FLOPs).  Algorithmic FLOPs per launch
     = 2 * B * (2H * 2W) * C_out * C_in * 4 taps (each output pixel of a 4x4 s2 p1 transposed conv has 2x2 taps);
@@ -96,7 +97,8 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     from locate_amd.models import generator_features
     feats = generator_features(cfg)
     rt = ops.Runtime()
-    rt.precision = 1 if bf16 else 0
+    rt.precision = 3 if fp8 else (1 if bf16 else 0)
+    bf16 = bf16 or fp8          # one matrix instruction per slice either way; the unscaled fp8 MFMA runs at the bf16 rate (MI355X_MICROARCH.md)
     total_flops, total_ms, rows, flops_list, alg_bytes = 0.0, 0.0, [], [], 0.0
     size = 2
     calls0 = ops.F16_CALLS["fwd"]
@@ -135,7 +137,9 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False):
     traffic, source = (None, "not collected for the bf16 variant") if bf16 else _pmc_traffic(flops_list)
     per_madd = 1 if bf16 else (3 if f16 else 6)
     peak = round(2500.0 / per_madd, 1)
-    if bf16:
+    if fp8:
+        kernel = "conv_igemm_fp8_kernel (implicit GEMM, e4m3 operands with per-tensor power-of-two scales, one v_mfma_f32_32x32x16_fp8_fp8 per slice - the bf16 rate -, fp32 accumulate, ConvTranspose 4x4 s2 fwd)"
+    elif bf16:
         kernel = "conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 slice, fp32 accumulate, ConvTranspose 4x4 s2 fwd)"
     elif f16:
         kernel = ("conv_igemm_bx6_kernel<NP=2> (implicit GEMM, fp32-faithful: 2 x fp16 scaled operand pieces, 3 fp16 MFMAs per 32x32x16 "
@@ -392,11 +396,14 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (contractions fp32-faithful on the matrix cores: 2 x scaled fp16 operand pieces / 3 MFMAs per slice where the operand's "
                      "largest magnitude comes with it, else 3 x bf16 pieces / 6 MFMAs; fp32 accumulate)" if args.dtype == "fp32" else
-                     "bf16 (contraction operands rounded to bf16, one MFMA per slice, fp32 accumulate; storage, statistics, "
-                     "sigma, activations and Nadam fp32) - NOT the headline line, see --dtype fp32", "data": "synthetic",
+                     ("bf16 (contraction operands rounded to bf16, one MFMA per slice, fp32 accumulate; storage, statistics, "
+                      "sigma, activations and Nadam fp32) - NOT the headline line, see --dtype fp32" if args.dtype == "bf16" else
+                      "fp8 (contraction operands as OCP e4m3 with per-tensor power-of-two scales on v_mfma_f32_32x32x16_fp8_fp8, fp32 "
+                      "accumulate; storage, statistics, sigma, activations and Nadam fp32; BASELINE configs[4]'s arithmetic, tolerances "
+                      "in tests/test_gpu_fp8.py) - NOT the headline line, see --dtype fp32"), "data": "synthetic",
             "config": {"workload": "LocAtE G+D step, %dx%d RGB, batch %d per GPU (%s of BASELINE.json configs[1]: 64x64 RGB bs 64), "
                                    "self/feature attention at 16x16 and 64x64, random-init weights"
-                                   % (S, S, B, "the fp32 variant - the reference's own precision -" if args.dtype == "fp32" else "the bf16 variant"),
+                                   % (S, S, B, "the fp32 variant - the reference's own precision -" if args.dtype == "fp32" else "the %s variant" % args.dtype),
                        "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" + ("" if args.no_overlap else ", G-step generator pass on a second stream")
                                   + (", weight gradients on a second stream" if step.overlap_wgrad else "")
@@ -408,7 +415,7 @@ def main():
         if comm is not None:
             line["data_parallel"] = comm
         if not args.step_only:
-            line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16")
+            line["roofline"] = conv_roofline(cfg, B, dev, bf16=args.dtype == "bf16", fp8=args.dtype == "fp8")
             if S == 64:
                 line["hbm_bound"] = hbm_bound_block(B, dev)
         if S == 64:

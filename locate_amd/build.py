@@ -15,7 +15,7 @@ LIB = os.path.join(CSRC, "liblocate_hip.so")
 # LOCATE_HIP_DEBUG_LIBRARY=1 is set before `import locate_amd`; the product library has no such switch compiled in.
 LIB_DBG = os.path.join(CSRC, "liblocate_hip_dbg.so")
 DBG_SOURCES = ["conv.hip", "convwin.hip"]
-SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "convwin.hip",
+SOURCES = ["runtime.hip", "elementwise.hip", "norm.hip", "softmax.hip", "resample.hip", "spectral.hip", "conv.hip", "convwin.hip", "convfp8.hip",
            "grouped.hip", "nadam.hip", "loss.hip", "finalise.hip", "parallel.hip"]
 ARCH = "gfx950"
 

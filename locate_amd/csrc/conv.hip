@@ -284,8 +284,28 @@ __device__ __forceinline__ void pack_split_body(const PackArgs& a, int bx, int n
     if (a.direct || a.win) return;     // direct form / window panels: the packing blocks wrote the planes
     const float* w = a.out;
     uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
-    const int64_t total = (int64_t)(a.rows / 8) * a.ld;
     const int64_t stride = (int64_t)nbx * 256;
+    if (a.fmt == 2) {          // fp8: chunks of 16 consecutive k, e4m3 bytes of w * 2^k(absmax)
+        const float sc = pow2f(f8_scale_exp(*reinterpret_cast<const unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld))));
+        const int64_t total16 = (int64_t)(a.rows / 16) * a.ld;
+        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total16; i += stride) {
+            const int kb = (int)(i / a.ld), col = (int)(i - (int64_t)kb * a.ld);
+            unsigned wq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = w[(int64_t)(kb * 16 + 4 * q + j) * a.ld + col] * sc;
+                int t = 0;
+                t = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], t, false);
+                t = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], t, true);
+                wq[q] = (unsigned)t;
+            }
+            w3[i] = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        }
+        return;
+    }
+    const int64_t total = (int64_t)(a.rows / 8) * a.ld;
     if (a.fmt) {
         const float sc = pow2f(f16_scale_exp(*reinterpret_cast<const unsigned*>(a.out + panel_split_offset_dev(a.rows, a.ld))));
         for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += stride) {
@@ -1298,6 +1318,16 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     dim3 grid(sp.gx, sp.gy, p.nphase * p.ksplit);
     for (int i = 0; i < p.nphase; ++i)
         LOCATE_REQUIRE(round_up(p.M, bm) <= p.ph[i].ld, "%s: tile height %d does not divide the panel width %d", who, bm, p.ph[i].ld);
+    if (p.precision == 3) {          // fp8 operands (convfp8.hip): the same tiling and split plan, 32-deep stages
+        launch_fp8_igemm(p, grid, bm, st);
+        LOCATE_LAUNCH_CHECK(who);
+        if (p.ksplit > 1 && !p.combine) {
+            LOCATE_REQUIRE(p.slab_stride < (1ll << 31), "%s: split-K output of %lld elements exceeds the 32-bit index range", who, p.slab_stride);
+            launch_slab_reduce(p, st);
+            LOCATE_LAUNCH_CHECK(who);
+        }
+        return LOCATE_OK;
+    }
     // launches of at most ~one block per CU: the eight-wave form (see the kernel)
     const bool w8 = !path_disabled("w8") && !path_disabled("bx6") && (bm == 128 || bm == 64) &&
                     (long long)grid.x * grid.y * grid.z <= knob_int("LOCATE_W8_MAX", 320);
@@ -1568,7 +1598,8 @@ static int conv_plan(const ConvGeom& g, int adjoint_fmt, const float* w, float* 
                      size_t* panel_floats_out, bool pack, hipStream_t st, PackBatch* batch_out = nullptr) {
     // adjoint_fmt: bit 0 = direction (0: R, 1: its data adjoint), bit 1 = panel format (0: bf16 planes, 1: fp16-piece planes),
     // bit 2 = window panel (chunk rows in unit order for the LDS-window kernels of convwin.hip; win_finish below)
-    const int adjoint = adjoint_fmt & 1, fmt = (adjoint_fmt >> 1) & 1;
+    // bit 3 = fp8 panel (one e4m3 plane, convfp8.hip)
+    const int adjoint = adjoint_fmt & 1, fmt = (adjoint_fmt & 8) ? 2 : ((adjoint_fmt >> 1) & 1);
     size_t off = 0;
     int nmax = 0;
     p.nphase = 0;
@@ -1688,7 +1719,7 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
             if (weight_absmax && (adjoint & 2)) { batch.ph[i].wmax = static_cast<const unsigned*>(weight_absmax); batch.ph[i].wmax_single = 0; }
             batch.ph[i].direct = (weight_absmax || !(adjoint & 2)) ? 1 : 0;
         }
-    } else if (direct && (weight_absmax || !(adjoint & 2))) {
+    } else if (direct && !(adjoint & 8) && (weight_absmax || !(adjoint & 2))) {          // (fp8 panels: always the two-pass form)
         const PackArgs& a0 = batch.ph[0];
         const bool transpose = a0.mode == 0 && p.nphase == 1;
         const bool adj = a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS;
@@ -1759,14 +1790,15 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
                      int precision, const unsigned* in_absmax, hipStream_t st, const char* who, const LocateActEpilogue* epi = nullptr) {
     const int win = (precision >> 4) & 1;          // bit 4: the panel is a window panel (locate_conv_win_ok)
     precision &= 15;
-    LOCATE_REQUIRE(precision >= 0 && precision <= 2, "%s: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)", who);
-    LOCATE_REQUIRE(precision != 2 || in_absmax, "%s: precision 2 needs the gathered tensor's absmax word", who);
+    LOCATE_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands), 2 (fp32-faithful, fp16 pieces) or 3 (fp8 operands)", who);
+    LOCATE_REQUIRE(precision < 2 || in_absmax, "%s: precisions 2 and 3 need the gathered tensor's absmax words", who);
+    LOCATE_REQUIRE(!(win && precision == 3), "%s: no window form of the fp8 contractions", who);
     IgParams p;
     p.precision = precision;
     p.b_absmax = in_absmax;
     p.act_out = nullptr; p.act_bs = 0; p.lat = nullptr; p.lat_bs = 0; p.lat_z = 0;
     int nmax = 0;
-    if (int e = conv_plan(g, (adjoint & 1) | (win ? 4 : 0) | (precision == 2 ? 2 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
+    if (int e = conv_plan(g, (adjoint & 1) | (win ? 4 : 0) | (precision == 2 ? 2 : 0) | (precision == 3 ? 8 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     LOCATE_REQUIRE(!win || ((in_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0), "%s: the window form loads pixel pairs: 8-byte aligned tensor, even batch stride", who);
     LOCATE_REQUIRE(!win || !(epi && epi->act_out), "%s: no activated second output in the window form", who);
@@ -2105,6 +2137,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
                                       // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
                                       // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
+// NP = 4: fp8 operands (BASELINE configs[4]) - both operands scaled into e4m3's range and rounded to e4m3 (v_cvt_pk_fp8_f32, the
+// arithmetic of convfp8.hip), then fed to the bf16 MFMA, in which every e4m3 value is exact: the products and the fp32 accumulation
+// are those of an fp8 MFMA, on this kernel's bf16 LDS images (the reduction index n needs pairs, which the 16-bit layout provides).
 template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands; NP = 2: two scaled fp16 pieces (see conv_igemm_bx6_kernel)
 __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
@@ -2113,8 +2148,9 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     constexpr int X_PT = BR / 32;
     static_assert(WGM * WGN == 4, "four waves");
 
-    __shared__ unsigned Gs[2][NP][BM][WB_PITCH];
-    __shared__ unsigned Xs[2][NP][BR][WB_PITCH];
+    constexpr int NPL = NP == 4 ? 1 : NP;          // piece planes in LDS
+    __shared__ unsigned Gs[2][NPL][BM][WB_PITCH];
+    __shared__ unsigned Xs[2][NPL][BR][WB_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -2175,6 +2211,20 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         g_scale = pow2f(kg_); g_unscale = pow2f(-kg_);
         x_scale = pow2f(kx_); x_unscale = pow2f(-kx_);
     }
+    if constexpr (NP == 4) {
+        const float gmax = __uint_as_float(absmax_read(p.g_absmax)) * fmaxf(fmaxf(gs0, gs1), fmaxf(gs2, gs3));
+        const int kg_ = f8_scale_exp(__float_as_uint(gmax) + (p.gscale_bg > 0 ? 0x00800000u : 0u));
+        const int kx_ = f8_scale_exp(absmax_read(p.x_absmax));
+        g_scale = pow2f(kg_); g_unscale = pow2f(-kg_);
+        x_scale = pow2f(kx_); x_unscale = pow2f(-kx_);
+    }
+    // a pair of values rounded to e4m3 and back (exact in bf16), packed as bf16
+    auto q8_pair = [](float v0, float v1) {
+        const int t = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(t, false);
+        return round_bf16_pair(r[0], r[1]);
+    };
 
     float2 greg[G_PT], xreg[X_PT];
     auto load_tiles = [&](int nb) {
@@ -2227,6 +2277,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
                 Gs[buf][0][sub + 32 * i][wcol] = h;
                 Gs[buf][NP - 2][sub + 32 * i][wcol] = m;
                 Gs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else if constexpr (NP == 4) {
+                Gs[buf][0][sub + 32 * i][wcol] = q8_pair(greg[i].x * gsc * g_scale, greg[i].y * gsc * g_scale);
             } else {
                 Gs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(greg[i].x * gsc, greg[i].y * gsc);
             }
@@ -2244,6 +2296,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
                 Xs[buf][0][sub + 32 * i][wcol] = h;
                 Xs[buf][NP - 2][sub + 32 * i][wcol] = m;
                 Xs[buf][NP - 1][sub + 32 * i][wcol] = l;
+            } else if constexpr (NP == 4) {
+                Xs[buf][0][sub + 32 * i][wcol] = q8_pair(xreg[i].x * x_scale, xreg[i].y * x_scale);
             } else {
                 Xs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(xreg[i].x, xreg[i].y);
             }
@@ -2266,15 +2320,15 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     using frag_t = typename std::conditional<NP == 2, f16x8, bf16x8>::type;
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        frag_t a[TM][NP], b[TN][NP];
+        frag_t a[TM][NPL], b[TN][NPL];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NPL; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+            for (int q = 0; q < NPL; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -2306,7 +2360,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         mfmas(HALF, NMF);
         __syncthreads();
     }
-    if constexpr (NP == 2) {
+    if constexpr (NP == 2 || NP == 4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -3159,8 +3213,8 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
                                  void* deferred_reduce, void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_wgrad")) return e;
-    LOCATE_REQUIRE(precision >= 0 && precision <= 2, "locate_conv_wgrad: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands) or 2 (fp32-faithful, fp16 pieces)");
-    LOCATE_REQUIRE(precision != 2 || (x_absmax && gy_absmax), "locate_conv_wgrad: precision 2 needs the absmax words of x and gy");
+    LOCATE_REQUIRE(precision >= 0 && precision <= 3, "locate_conv_wgrad: precision must be 0 (fp32-faithful, bf16 pieces), 1 (bf16 operands), 2 (fp32-faithful, fp16 pieces) or 3 (fp8 operands)");
+    LOCATE_REQUIRE(precision < 2 || (x_absmax && gy_absmax), "locate_conv_wgrad: precisions 2 and 3 need the absmax words of x and gy");
     LOCATE_REQUIRE(x && gy && gw, "locate_conv_wgrad: null pointer");
     LOCATE_REQUIRE(!inner_partial || w_ref, "locate_conv_wgrad: inner_partial needs w_ref");
     // stacked calls with w_ref + inner_partial: the per-call dots come out of the split reduction (locate_conv_wgrad_group_partials)
@@ -3255,7 +3309,12 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     // pairs of adjacent reduction elements: same image and same output row, 8-byte aligned in gy
     const bool pairs_ok = ((g.OH * g.OW) & 1) == 0 && (g.OW & 1) == 0 && (gy_bs & 1) == 0 && (chunk & 1) == 0 &&
                           (reinterpret_cast<uintptr_t>(gy) & 7) == 0 && x_extent > 0 && x_extent < (1ll << 31) - (1 << 20);
-    if (pairs_ok && precision == 1) {
+    if (precision == 3 && pairs_ok) {          // (odd output maps: the exact fp32-MFMA kernel below, at every precision setting)
+        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 4><<<grid, 256, 0, st>>>(p);
+        else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 4><<<grid, 256, 0, st>>>(p);
+        else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 4><<<grid, 256, 0, st>>>(p);
+        else conv_wgrad_bx6_kernel<1, 4, 1, 1, 4><<<grid, 256, 0, st>>>(p);
+    } else if (pairs_ok && precision == 1) {
         if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);

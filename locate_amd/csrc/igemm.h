@@ -93,7 +93,9 @@ struct PackArgs {
 // fmt 0: the split section holds the three bf16 planes; fmt 1 ("fp16 pieces", see conv_igemm_bx6_kernel NP = 2): a 4-dword
 // header {absmax bits of this phase's weights, 0, 0, 0} followed by TWO fp16 planes of the weights times 2^k(absmax)
 #define PANEL_HDR 4
+// fmt 2 ("fp8", convfp8.hip): the same header followed by ONE plane of e4m3 bytes, 16 consecutive k per 16-byte chunk
 static inline size_t panel_floats(int rows, int ld, int fmt) {
+    if (fmt == 2) return (size_t)rows * ld + rows + rows / 4 + PANEL_HDR + (size_t)rows * ld / 4;
     return (size_t)rows * ld + rows + rows / 4 + (fmt ? PANEL_HDR + (size_t)rows * ld / 2 * 2 : (size_t)rows * ld / 2 * 3);
 }
 static inline size_t panel_split_offset(int rows, int ld) { return (size_t)rows * ld + rows + rows / 4; }   // floats
@@ -108,6 +110,13 @@ __host__ __device__ __forceinline__ int f16_scale_exp(unsigned bits) {
     const int e = (int)((bits >> 23) & 0xffu) - 127;
     if (e == -127) return 0;
     const int k = 14 - e;
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+// the same for e4m3 operands (largest finite value 448): absmax * 2^k in [2^7, 2^8)
+__host__ __device__ __forceinline__ int f8_scale_exp(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu) - 127;
+    if (e == -127) return 0;
+    const int k = 7 - e;
     return k > 100 ? 100 : (k < -100 ? -100 : k);
 }
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }      // -126 <= k <= 127
@@ -452,5 +461,6 @@ static inline __host__ __device__ int win_pack_rg(int KK) { return KK == 1 ? 64 
 static inline size_t win_panel_floats(int urows, int ld, int fmt) { return PANEL_HDR + (size_t)(fmt ? 2 : 3) * urows * ld * 4; }
 
 int launch_win_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who);
+void launch_fp8_igemm(const IgParams& p, dim3 grid, int bm, hipStream_t st);
 size_t win_slab_floats(const IgParams& p, int nmax);
 void launch_slab_reduce(const IgParams& p, hipStream_t st);

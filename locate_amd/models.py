@@ -149,8 +149,10 @@ class _NetBase(nn.Module):
     def set_precision(self, name):
         """"fp32": the reference's arithmetic (default; contractions as exact three-piece bf16 splits, six MFMAs per slice).
         "bf16": contraction operands rounded to bf16, one MFMA per slice, fp32 accumulation; everything else - storage,
-        statistics, sigma, RootTanh, the optimizer - stays fp32 (the mixed-precision variant BASELINE.json configs[1] names)."""
-        self.runtime.precision = {"fp32": 0, "f32": 0, "bf16": 1}[name]
+        statistics, sigma, RootTanh, the optimizer - stays fp32 (the mixed-precision variant BASELINE.json configs[1] names).
+        "fp8": both operands of every dense contraction as OCP e4m3 with per-tensor power-of-two scales on the fp8 matrix
+        instruction (csrc/convfp8.hip; BASELINE.json configs[4]), fp32 accumulation, everything else fp32 as for "bf16"."""
+        self.runtime.precision = {"fp32": 0, "f32": 0, "bf16": 1, "fp8": 3}[name]
         return self
 
     def adopt(self):

@@ -165,6 +165,19 @@ def carry_amax(src, view):
     return view
 
 
+def _ensure_amax(t):
+    """t's largest-magnitude words: the producer's, or - a tensor that came without (small maps, foreign producers) - from a pass
+    of its own (the fp8 form cannot fall back to an unscaled arithmetic the way the fp16-piece form falls back to six products)."""
+    a = _amax_of(t)
+    if a is None:
+        a = AMAX.slot(t.device)
+        if a is None:
+            raise RuntimeError("fp8 contractions need the largest-magnitude arena (ops.AMAX.enabled)")
+        tc = t if _dense_planes(t) and t.is_contiguous() else t.contiguous()
+        check(lib().locate_absmax(_p(tc), tc.numel(), _p(a), _stream()), "locate_absmax")
+    return a
+
+
 def tag_amax(t):
     """Computes t's largest-magnitude word with a pass of its own and attaches it (tests, tools; the hot path gets the word from
     the kernel that produces the tensor)."""
@@ -1142,7 +1155,7 @@ def refresh_panels(params):
             if not L.locate_conv_pack_job_is_direct(ctypes.addressof(host) + i * rec):
                 # pass bits of locate_conv_pack_panels: 1 = split launch (gather-kernel panels), 2 = absmax pre-pass (window panels)
                 two_pass |= 2 if L.locate_conv_pack_job_is_window(ctypes.addressof(host) + i * rec) else 1
-                two_pass_f16 |= int(bool(key[0] & 2))
+                two_pass_f16 |= int(bool(key[0] & 10))          # fp16-piece and fp8 panels: their absmax headers are cleared first
         table = torch.frombuffer(host, dtype=torch.uint8).clone().to(stale[0][0].device)
         plan = (table, len(stale), start, two_pass_f16, two_pass)
         if len(_PackPlans.cache) > 16:
@@ -1243,6 +1256,7 @@ def _f16_ok(spec, geom, precision, *amax):
 # default = where locate_conv_win_ok says they are the measured choice
 WIN_MODE = {"0": 0, "all": 2}.get(os.environ.get("LOCATE_WINDOW", "1"), 1)
 WIN_CALLS = [0]                                                 # launches that took the window form (tests check the path is live)
+FP8_CALLS = [0]                                                 # forward / input-gradient launches with fp8 operands
 _WIN_CACHE = {}
 
 
@@ -1280,9 +1294,12 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
         prec, fmt, am = (2, 2, amax) if f16 else (precision, 0, None)
         if f16:
             F16_CALLS["fwd" if forward_of_r == (spec.kind == "conv") else "dgrad"] += 1
+        if precision == 3:               # fp8 operands (csrc/convfp8.hip): panel format bit 3, the gathered tensor's largest magnitude
+            prec, fmt, am = 3, 8, _ensure_amax(x)
+            FP8_CALLS[0] += 1
         adj = 0 if forward_of_r else 1
         # the window form (csrc/convwin.hip): the gathered operand staged in LDS once for all taps - where the geometry has it
-        win = epilogue is None and _win_ok(geom, garr, adj | fmt, x)
+        win = epilogue is None and precision != 3 and _win_ok(geom, garr, adj | fmt, x)
         if win:
             fmt |= 4
             prec |= 16
@@ -1360,8 +1377,11 @@ def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst
         rec = ctypes.create_string_buffer(L.locate_slab_reduce_record_bytes()) if defer else None
         f16 = _f16_ok(spec, geom, precision, amax_in, amax_out)
         F16_CALLS["wgrad"] += int(f16)
+        if precision == 3:               # fp8 operands: both activations' largest magnitudes
+            amax_in, amax_out = _ensure_amax(xin), _ensure_amax(gout)
+        scaled = f16 or precision == 3
         check(L.locate_conv_wgrad(garr, _p(xin), _bs(xin), _p(gout), _bs(gout), _p(gw), _p(w_ref), _p(inv_sigma), sbg, sst, _p(partial),
-                                  _p(ws), 2 if f16 else precision, _p(amax_in) if f16 else None, _p(amax_out) if f16 else None, rec, st),
+                                  _p(ws), 2 if f16 else precision, _p(amax_in) if scaled else None, _p(amax_out) if scaled else None, rec, st),
               "locate_conv_wgrad")
         if defer and L.locate_slab_reduce_record_blocks(rec) > 0:
             rt.queue_slab_reduce(rec.raw, (ws, gw, w_ref, inv_sigma, partial))
