@@ -74,7 +74,15 @@ __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf
 __device__ __forceinline__ void pack_emit_chunk(const PackArgs& a, const float (&v)[8], float sc, int64_t i) {
     const int64_t plane = (int64_t)(a.rows / 8) * a.ld;
     uint4* w3 = reinterpret_cast<uint4*>(a.out + panel_split_offset_dev(a.rows, a.ld) + (a.fmt ? PANEL_HDR : 0));
-    if (a.fmt) {
+    if (a.fmt == 2) {          // fp8 plane: 16-k chunks - this 8-k chunk is one half (8 bytes) of chunk (kb8 / 2, column)
+        const int64_t kb8 = i / a.ld, col = i - kb8 * a.ld;
+        int t0 = 0, t1 = 0;
+        t0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * sc, v[1] * sc, t0, false);
+        t0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * sc, v[3] * sc, t0, true);
+        t1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * sc, v[5] * sc, t1, false);
+        t1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * sc, v[7] * sc, t1, true);
+        reinterpret_cast<uint2*>(w3)[2 * ((kb8 >> 1) * a.ld + col) + (kb8 & 1)] = make_uint2((unsigned)t0, (unsigned)t1);
+    } else if (a.fmt) {
         uint4 h, l;
         split2_f16x8(v, sc, h, l);
         w3[i] = h;
@@ -149,7 +157,7 @@ __device__ __forceinline__ void pack_transpose_body(const PackArgs& a, int bx, i
         // direct form: the tile's 8 k-blocks x 64 columns as piece chunks, two per thread; consecutive threads write
         // consecutive 16-byte chunks of a plane row
         const unsigned bits = a.fmt ? absmax_read(a.wmax) : 0u;
-        const float sc = pow2f(f16_scale_exp(bits));
+        const float sc = pow2f(a.fmt == 2 ? f8_scale_exp(bits) : f16_scale_exp(bits));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int kb = (threadIdx.x >> 6) + 4 * q, m = m0 + tx;
@@ -202,7 +210,7 @@ __device__ __forceinline__ void pack_adjoint_direct_body(const PackBatch& batch,
     }
     __syncthreads();
     const unsigned bits = a0.fmt ? absmax_read(a0.wmax) : 0u;
-    const float sc = pow2f(f16_scale_exp(bits));
+    const float sc = pow2f(a0.fmt == 2 ? f8_scale_exp(bits) : f16_scale_exp(bits));
     // work items (phase, chunk, column), columns fastest: T chunks of 8 rows k = (m, tap) per phase for this block's 8 m
     int tsum = 0;
     for (int ph = 0; ph < nphase; ++ph) tsum += batch.ph[ph].TH * batch.ph[ph].TW;
@@ -1719,7 +1727,7 @@ LOCATE_API int locate_conv_pack_job(const int* geom, int adjoint, const float* w
             if (weight_absmax && (adjoint & 2)) { batch.ph[i].wmax = static_cast<const unsigned*>(weight_absmax); batch.ph[i].wmax_single = 0; }
             batch.ph[i].direct = (weight_absmax || !(adjoint & 2)) ? 1 : 0;
         }
-    } else if (direct && !(adjoint & 8) && (weight_absmax || !(adjoint & 2))) {          // (fp8 panels: always the two-pass form)
+    } else if (direct && (weight_absmax || !(adjoint & 10))) {          // (fp16-piece and fp8 panels need the weights' absmax words)
         const PackArgs& a0 = batch.ph[0];
         const bool transpose = a0.mode == 0 && p.nphase == 1;
         const bool adj = a0.mode == 1 && a0.KH * a0.KW <= PACK_MAX_TAPS;

@@ -153,6 +153,8 @@ class _NetBase(nn.Module):
         "fp8": both operands of every dense contraction as OCP e4m3 with per-tensor power-of-two scales on the fp8 matrix
         instruction (csrc/convfp8.hip; BASELINE.json configs[4]), fp32 accumulation, everything else fp32 as for "bf16"."""
         self.runtime.precision = {"fp32": 0, "f32": 0, "bf16": 1, "fp8": 3}[name]
+        if name == "fp8":
+            ops.AMAX_MIN_NUMEL[0] = 1          # every contraction operand's largest magnitude comes from its producer (process-wide)
         return self
 
     def adopt(self):

@@ -108,7 +108,7 @@ class _AmaxArena:
             if overflow and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("hipGraph capture needs more largest-magnitude word sets (%d) than the iteration's block holds: "
                                    "run one eager iteration of this configuration first (the block is sized from it)" % (self._step_used + 1))
-            self.cap = max(self.STEP_SLOTS, 2 * self.cap) if self._step else self.SLOTS
+            self.cap = self.STEP_SLOTS if self._step else self.SLOTS
             self.block = torch.zeros(self.cap * self.words, dtype=torch.int32, device=device)
             self.used = 0
             if overflow:
@@ -130,6 +130,10 @@ F16_MIN_FLOPS = 0.5e9
 
 
 F16_CALLS = {"fwd": 0, "dgrad": 0, "wgrad": 0}      # launches that took the fp16-piece form (tests check the path is live)
+# producers leave their output's largest magnitude from this many elements up: below it no contraction of F16_MIN_FLOPS follows.
+# The fp8 form needs EVERY operand's maximum (Model.set_precision("fp8") lowers this to 1: a producer's few extra words cost less than
+# the separate pass _ensure_amax would launch)
+AMAX_MIN_NUMEL = [1 << 16]
 
 
 def _tag(t, words):
@@ -209,7 +213,7 @@ class RootTanhFn(torch.autograd.Function):
         # a fresh buffer of its own: its largest magnitude rides along for the contraction that consumes it (a shared fan-out
         # buffer does not get one - the other branch still adds into it)
         # (only where a contraction of F16_MIN_FLOPS could consume it: 4-d maps of some size, like the forward's rule)
-        amax = AMAX.slot(x.device) if (ctx.slot is None and x.dim() >= 3 and x.numel() >= (1 << 16)) else None
+        amax = AMAX.slot(x.device) if (ctx.slot is None and x.dim() >= 3 and x.numel() >= AMAX_MIN_NUMEL[0]) else None
         check(lib().locate_roottanh_bwd(_p(x), _p(g), _p(gx), x.numel(), acc, _p(amax), _stream()), "locate_roottanh_bwd")
         if amax is not None:
             _tag(gx, amax)
@@ -270,7 +274,7 @@ class ActCatFn(torch.autograd.Function):
 def root_tanh(x):
     # the activation in front of a conv: its output's largest magnitude rides along for the contraction's fp16-piece form
     # (only worth a word where a contraction of F16_MIN_FLOPS could follow: 4-d maps, not the style chain's rows)
-    amax = AMAX.slot(x.device) if x.dim() >= 3 and x.numel() >= (1 << 16) else None
+    amax = AMAX.slot(x.device) if x.dim() >= 3 and x.numel() >= AMAX_MIN_NUMEL[0] else None
     y = RootTanhFn.apply(x, _slot_of(x) if x.is_contiguous() else None, amax)
     if amax is not None:
         _tag(y, amax)
@@ -775,7 +779,7 @@ def inplace_norm(x, scale, bias, with_act=False, runtime=None):
     pre_partial = pre[0] if (pre is not None and pre[1] == groups and x.is_contiguous()) else None
     # the output's largest magnitude for the fp16-piece form of the contraction that consumes it (a conv stage behind
     # norm + RootTanh, the position gate's first 1x1 conv behind a plain norm)
-    amax = AMAX.slot(x.device) if x.numel() >= (1 << 16) else None
+    amax = AMAX.slot(x.device) if x.numel() >= AMAX_MIN_NUMEL[0] else None
     out = InPlaceNormFn.apply(x, scale, bias, with_act, groups, pre_partial, _slot_of(x) if x.is_contiguous() else None, amax, runtime)
     if amax is not None:
         _tag(out, amax)
@@ -832,7 +836,7 @@ class GateFn(torch.autograd.Function):
         dgamma = torch.empty_like(gamma) if need_gamma else None
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
         # full-map form: da goes straight into the branch's last conv (its data and weight gradients) - with its largest magnitude
-        amax = AMAX.slot(x.device) if (not ctx.per_plane and da.numel() >= (1 << 16)) else None
+        amax = AMAX.slot(x.device) if (not ctx.per_plane and da.numel() >= AMAX_MIN_NUMEL[0]) else None
         check(L.locate_gate_bwd(_p(x), _p(a), int(ctx.per_plane), _p(gamma), _p(g), _p(dx), _p(da), None if deferred else _p(dgamma),
                                 planes, hw, _p(ws), acc, _p(amax), _stream()), "locate_gate_bwd")
         if amax is not None:
@@ -1138,7 +1142,7 @@ def refresh_panels(params):
         hold = w.__dict__.get("_locate_wmax") if DIRECT_REPACK else None
         return hold[0].data_ptr() if (hold is not None and hold[1] == w._version and hold[0].device == w.device) else None
 
-    wm = [wmax_of(w) if key[0] & 2 else None for w, key, _, _ in stale]
+    wm = [wmax_of(w) if key[0] & 10 else None for w, key, _, _ in stale]          # (fp16-piece and fp8 panels are scaled)
     direct = int(DIRECT_REPACK)          # bf16-piece panels need no scale: always one pass
     sig = tuple((key[2], key[0], buf.data_ptr(), m, direct) + tuple(geom) for (_, key, buf, geom), m in zip(stale, wm))
     plan = _PackPlans.cache.get(sig)

@@ -7,7 +7,7 @@ path = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
 files = glob.glob(path + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(files[0])))
-cats = [("conv igemm", lambda n: "conv_igemm" in n or "conv_pointwise" in n), ("conv wgrad", lambda n: "conv_wgrad" in n or "pw_wgrad" in n),
+cats = [("conv igemm", lambda n: "conv_igemm" in n or "conv_pointwise" in n or "conv_win" in n), ("conv wgrad", lambda n: "conv_wgrad" in n or "pw_wgrad" in n),
         ("conv 1x1 maps", lambda n: "skinny_" in n),
         ("slab reduce", lambda n: "slab_reduce" in n), ("panel pack", lambda n: "pack_" in n),
         ("spectral norm", lambda n: n.startswith("void sn_") or n.startswith("sn_")),
