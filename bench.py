@@ -322,11 +322,12 @@ def main():
         late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
         # the D-step's backward runs in two segments cut behind the discriminator's block 2 (maps >= 8x8 | <= 4x4): the deep
         # segment holds ~95 % of D's parameters and is on the wire while the high-resolution segment's backward runs
-        d_cut = 3 if len(D.main[1].blocks) > 3 else None
+        d_cut = 3 if (len(D.main[1].blocks) > 3 and os.environ.get("LOCATE_DP_NOCUT") != "1") else None      # (experiment switch)
         solo = int(os.environ.get("LOCATE_DP_SOLO_BYTES", "0"))     # > 0: gradients from this size up are all-reduced in place
-        red_g = GradAllReducer(G.parameters(), force=force_dp, solo_bytes=solo)
+        bucket = int(os.environ.get("LOCATE_DP_BUCKET_MB", "128")) << 20   # one collective per backward segment at config 2
+        red_g = GradAllReducer(G.parameters(), force=force_dp, solo_bytes=solo, bucket_bytes=bucket)
         red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp,
-                               solo_bytes=solo)
+                               solo_bytes=solo, bucket_bytes=bucket)
     wgrad_overlap = False if (args.no_wgrad_overlap or args.wgrad_overlap == "off") else (True if args.wgrad_overlap == "on" else bool(dp))
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
                      overlap_wgrad=wgrad_overlap, d_cut=d_cut)
@@ -366,7 +367,9 @@ def main():
         tg, xg = red_g.pop_timing()
         td, xd = red_d.pop_timing()
         red_g.timing = red_d.timing = False
-        comm = {"allreduce_ms_per_step": {"D": round(td / 5, 4), "G": round(tg / 5, 4)},
+        comm = {"buckets_sent": {"D": {"in_place": red_d.sent_in_place, "packed": red_d.sent_packed},
+                                 "G": {"in_place": red_g.sent_in_place, "packed": red_g.sent_packed}},
+                "allreduce_ms_per_step": {"D": round(td / 5, 4), "G": round(tg / 5, 4)},
                 "exposed_ms_per_step": {"D": round(xd / 5, 4), "G": round(xg / 5, 4)},
                 "payload_MB": {"D": round(sum(p.numel() for p in D.parameters()) * 4 / 1e6, 1),
                                "G": round(sum(p.numel() for p in G.parameters()) * 4 / 1e6, 1)},

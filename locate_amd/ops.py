@@ -327,6 +327,7 @@ class Runtime:
         self._fin_wgrad = []             # packed SkwRec records (conv.hip): the pass's small-map weight gradients
         self._fin_slab = []              # packed SlabRec records (conv.hip): the split reductions of its other weight gradients
         self._streams = {}               # streams on which this pass queued deferred work / produced late gradients
+        self._homes_taken = set()        # parameters whose bucket home (see _grad_home) a gradient of this pass already occupies
 
     # the copy of a network (copy.deepcopy in tests, DP replicas) gets a fresh runtime state, never the streams / tables
     def __deepcopy__(self, memo):
@@ -352,6 +353,7 @@ class Runtime:
         self._side_results = []
         self._keep = []
         self._streams = {}
+        self._homes_taken = set()
         AMAX.new_pass()
         self._fin_dots, self._fin_rank1, self._fin_sums, self._fin_chan, self._fin_norm = [], [], [], [], []
         self._fin_wgrad, self._fin_slab = [], []
@@ -408,10 +410,11 @@ class Runtime:
         results, self._side_results = self._side_results, []
         self._keep = []
         for param, grad in results:
-            if param.grad is None:
-                param.grad = grad
+            if param.grad is None or param.grad.data_ptr() == grad.data_ptr():
+                param.grad = grad                 # (a gradient written to the parameter's bucket home is the .grad tensor itself)
             else:
                 param.grad.add_(grad)
+        self._homes_taken = set()
         self._finalize_dv()
 
     _FIN = __import__("struct").Struct("<8Q2q8i")
@@ -476,6 +479,9 @@ class Runtime:
             st = {"dv": torch.empty_like(v_param.detach()), "dsig": torch.zeros(4, dtype=torch.float32, device=v_param.device),
                   "scratch": torch.empty(wd + h + nch * wd, dtype=torch.float32, device=v_param.device), "k": 0}
             v_param.__dict__["_locate_dv"] = st
+        home = v_param.__dict__.get("_locate_grad_buf")
+        if home is not None and home.device == v_param.device and st["dv"].data_ptr() != home.data_ptr():
+            st["dv"] = home.view(st["dv"].shape)          # v's gradient lives in its data-parallel bucket (see _grad_home)
         k = st["k"]
         if k >= 4:
             raise RuntimeError("a spectral-norm layer was differentiated through more than 4 forwards in one backward pass")
@@ -568,6 +574,18 @@ class _Deferral:
     def __exit__(self, *exc):
         self.rt.defer_finalisers = self.prev
         return False
+
+
+def _grad_home(rt, param, shape=None):
+    """The buffer a parameter's gradient of this backward pass is written to: the parameter's HOME inside its data-parallel
+    bucket (parallel.GradAllReducer.make_homes: a view of the bucket's resident flat buffer - the bucket is then all-reduced
+    where it lies, nothing is packed or scattered) if it has one and nobody has claimed it in this pass yet, else a fresh tensor."""
+    shape = tuple(param.shape if shape is None else shape)
+    home = param.__dict__.get("_locate_grad_buf") if param is not None and hasattr(param, "__dict__") else None
+    if home is not None and home.device == param.device and home.numel() == param.numel() and id(param) not in rt._homes_taken:
+        rt._homes_taken.add(id(param))
+        return home.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
 
 
 DEFAULT_RUNTIME = Runtime()     # layers used on their own (not inside a Generator / Discriminator)
@@ -755,8 +773,8 @@ class InPlaceNormFn(torch.autograd.Function):
             dscale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device) if ctx.per_sample else None
             check(L.locate_norm_bwd_fused(_p(x), _p(g), _p(stats), _p(scale), int(ctx.per_sample), _p(bias), int(ctx.with_act), _p(dx),
                                           _p(dscale), B, C, hw, ctx.groups, _p(ws), acc, st), "locate_norm_bwd_fused")
-            late_scale = torch.empty(ctx.scale_shape, dtype=torch.float32, device=x.device) if (need_scale and not ctx.per_sample) else None
-            late_bias = torch.empty(ctx.bias_shape, dtype=torch.float32, device=x.device) if need_bias else None
+            late_scale = _grad_home(rt, ctx.scale_in, ctx.scale_shape) if (need_scale and not ctx.per_sample) else None
+            late_bias = _grad_home(rt, ctx.bias_in, ctx.bias_shape) if need_bias else None
             if late_scale is not None or late_bias is not None:
                 rt.queue_norm_channels(ws, L.locate_norm_bwd_fused_plane_offset(), B * C, stats, late_scale, late_bias, B, C, ctx.groups)
                 if late_scale is not None:
@@ -833,7 +851,7 @@ class GateFn(torch.autograd.Function):
         # d(gamma) only feeds the parameter's gradient: with deferral its final sum joins the pass's batched finalisers and
         # the result is assigned at the end of the pass; a frozen gamma (the G-step's discriminator pass) needs none at all
         deferred = need_gamma and rt.defer_finalisers and ctx.gamma_param.is_leaf
-        dgamma = torch.empty_like(gamma) if need_gamma else None
+        dgamma = (_grad_home(rt, ctx.gamma_param, gamma.shape) if deferred else torch.empty_like(gamma)) if need_gamma else None
         ws = _ws(L.locate_gate_bwd_workspace_bytes(planes), x.device)
         # full-map form: da goes straight into the branch's last conv (its data and weight gradients) - with its largest magnitude
         amax = AMAX.slot(x.device) if (not ctx.per_plane and da.numel() >= AMAX_MIN_NUMEL[0]) else None
@@ -1409,7 +1427,8 @@ def _weight_grad_partials(spec, geom, garr):
     return L.locate_groupdot_wgrad_partials(geom[1], geom[2])
 
 
-def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v, amax_x=None, amax_gy=None):
+def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, geom, garr, need_u, need_v, amax_x=None, amax_gy=None,
+                      owner=None):
     """dW_bar (incl. the rank-1 spectral-norm term) and du; dv is batched over the whole backward pass
     (Runtime.defer_dv).  y / bias are only read for stacked calls (<G_k, W_bar> taken on the activation side).
     With rt.defer_finalisers the rank-1 term, du and dsigma (and the stacked calls' dots) are only QUEUED here: the returned
@@ -1417,13 +1436,13 @@ def _conv_weight_grad(rt, x, gy, y, bias, w, u_param, v_param, sigma, wv, spec, 
     L = lib()
     st = _stream()
     groups, sbg, sst, inv_sigma = _sigma_args(sigma, x.shape[0])
-    gw = torch.empty_like(w)
+    gw = _grad_home(rt, owner, w.shape) if (owner is not None and owner.is_leaf) else torch.empty_like(w)
     xin, gout = (x, gy) if spec.kind == "conv" else (gy, x)    # transposed: R's input is gy, its output-gradient x
     am_in, am_out = (amax_x, amax_gy) if spec.kind == "conv" else (amax_gy, amax_x)
     h = w.shape[0]
     wd = w.numel() // h
     u, v = u_param.detach(), v_param.detach()
-    gu = torch.empty_like(u) if need_u else None
+    gu = (_grad_home(rt, u_param) if u_param.is_leaf else torch.empty_like(u)) if need_u else None
     if groups > 1:
         # gw = sum_k G_k / sigma_k in one pass (gy weighted per call while it is loaded); dsigma_k from
         # <gy_k, y_k - bias>; rank-1 correction with the summed dsigma
@@ -1579,12 +1598,12 @@ class SNConvFn(torch.autograd.Function):
             late = side is not None or rt.defer_finalisers     # the gradients bypass autograd: assigned at the end of the pass
             if side is None:
                 sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v,
-                                             ctx.amax_x, amax_gy)
+                                             ctx.amax_x, amax_gy, ctx.owner if late else None)
             else:
                 side.wait_stream(torch.cuda.current_stream())        # gy (and x) are complete on the pass's stream
                 with torch.cuda.stream(side):
                     sgw, sgu = _conv_weight_grad(rt, x, gy, y, bsaved, w, ctx.u, ctx.v, sigma, wv, spec, ctx.geom, garr, need_u, need_v,
-                                                 ctx.amax_x, amax_gy)
+                                                 ctx.amax_x, amax_gy, ctx.owner if late else None)
                 rt._side = side
             if late:
                 rt._keep.append((x, gy, y, bsaved, w, sigma, wv))
@@ -1597,7 +1616,7 @@ class SNConvFn(torch.autograd.Function):
                 gw, gu = (sgw if need_w else None), sgu
         if ctx.has_bias and need_b:
             if ctx.rt.defer_finalisers and ctx.bias_param.is_leaf:
-                late_gb = torch.empty(gy.shape[1], dtype=torch.float32, device=gy.device)
+                late_gb = _grad_home(ctx.rt, ctx.bias_param, (gy.shape[1],))
                 ctx.rt.queue_channel_sum(gy, late_gb)
                 ctx.rt.late_grad(ctx.bias_param, late_gb.view(ctx.bias_param.shape))
             else:

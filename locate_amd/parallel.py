@@ -122,6 +122,12 @@ class GradAllReducer:
             for i in idxs:
                 self.bucket_of[i] = b
         self._flat = [None] * len(self.buckets)
+        # resident bucket memory: every parameter's gradient has a HOME inside its bucket's flat buffer (`_locate_grad_buf`, a view);
+        # the backward kernels of this package write parameter gradients there (ops._grad_home), so a bucket whose gradients all
+        # sit at home is all-reduced where it lies - no packing before, no scattering after the collective
+        self.sent_in_place = self.sent_packed = 0          # buckets sent from their resident buffer / through a packed copy (bench.py)
+        self._home = [None] * len(self.buckets)
+        self._home_off = {}
         self._handles = []
         self._ready = None
         self._launched = None
@@ -184,9 +190,12 @@ class GradAllReducer:
         grads = [self.params[i].grad for i in members]
         dev = grads[0].device
         total = sum(g.numel() for g in grads)
-        in_place = self._in_place(b, grads)
+        own = self._in_place(b, grads, members)
+        in_place = own is not None
+        self.sent_in_place += int(in_place)
+        self.sent_packed += int(not in_place)
         if in_place:
-            flat = grads[0].view(-1)            # the gradient itself: reduced where it lies
+            flat = own                          # the gradient itself / the resident bucket: reduced where it lies
         else:
             flat = self._flat[b]
             if flat is None or flat.numel() != total or flat.device != dev:
@@ -210,8 +219,39 @@ class GradAllReducer:
             work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
         self._handles.append((b, members, work, flat if in_place else None))
 
-    def _in_place(self, b, grads):
-        return self.bucket_solo[b] and len(grads) == 1 and grads[0].is_contiguous()
+    def _in_place(self, b, grads, members=None):
+        """The tensor to all-reduce in place, or None: a solo gradient itself; or the bucket's resident buffer when every gradient
+        of the bucket lies at its home inside it (slots of parameters without a gradient ride along unread)."""
+        if self.bucket_solo[b] and len(grads) == 1 and grads[0].is_contiguous():
+            return grads[0].view(-1)
+        home = self._home[b]
+        if home is None or members is None or not grads or home.device != grads[0].device:
+            return None
+        base = home.data_ptr()
+        for i, g in zip(members, grads):
+            if not g.is_contiguous() or g.data_ptr() != base + 4 * self._home_off[i] or g.dtype != torch.float32:
+                return None
+        return home
+
+    def make_homes(self):
+        """Creates the resident bucket buffers and points every parameter at its slice (idempotent; call once the parameters are
+        on their device - TrainStep does, before the first backward pass)."""
+        if not self.enabled:
+            return
+        for b, idxs in enumerate(self.buckets):
+            if self._home[b] is not None or not idxs or self.bucket_solo[b]:
+                continue
+            ps = [self.params[i] for i in idxs]
+            dev = ps[0].device
+            if any(q.device != dev or q.dtype != torch.float32 for q in ps):
+                continue
+            home = torch.zeros(sum(q.numel() for q in ps), dtype=torch.float32, device=dev)
+            off = 0
+            for i, q in zip(idxs, ps):
+                self._home_off[i] = off
+                q.__dict__["_locate_grad_buf"] = home[off:off + q.numel()].view(q.shape)
+                off += q.numel()
+            self._home[b] = home
 
     def _check_agreement(self, b, members):
         """Which parameters have a gradient is decided per rank (`grad is not None`); ranks that disagreed would exchange
@@ -383,8 +423,8 @@ class GradAllReducer:
                 continue
             grads = [self.params[i].grad for i in members]
             self._check_agreement(b, members)
-            if self._in_place(b, grads):
-                own = grads[0].view(-1)
+            own = self._in_place(b, grads, members)
+            if own is not None:
                 dist.all_reduce(own, op=self._op(), group=self.group)
                 if inv is not None:
                     own.mul_(inv)

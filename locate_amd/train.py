@@ -69,6 +69,9 @@ class TrainStep:
         self.penalty_gamma = penalty_gamma
         self.minibatches = minibatches
         self.reducer_g, self.reducer_d = reducer_g, reducer_d
+        for red in (reducer_g, reducer_d):
+            if red is not None:
+                red.make_homes()         # parameter gradients are produced inside their buckets' resident buffers (parallel.py)
         # concurrent_d: run the D-step's three discriminator passes (and the generator forward feeding the second)
         # on three HIP streams.  Most of the step's ~1900 launches are tiny, launch-latency-bound kernels; three
         # independent chains side by side fill the chip where one cannot.  Needs the batched spectral norm (the power

@@ -141,6 +141,34 @@ def _worker_modes(rank, world, port, mode, q):
             ok = all(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 + i)) for i, p in enumerate(params))
             red.reduce_now()                                                   # the same values averaged again: sum of x / ... stays put
             q.put((rank, ok, ""))
+        elif mode == "homes":
+            # gradients produced INSIDE the buckets' resident buffers (make_homes: what ops._grad_home does on the GPU): such a bucket
+            # is all-reduced where it lies - no flat copy is created; a parameter without a gradient (index 1 in the second round)
+            # leaves its slot unread and its .grad None; a gradient that is NOT at home sends its bucket through the packed path
+            red = GradAllReducer(params, bucket_bytes=40)              # buckets in reverse parameter order: [2, 1] (3 + 7 floats) | [0]
+            assert red.buckets == [[2, 1], [0]]
+            red.make_homes()
+            assert all("_locate_grad_buf" in q_.__dict__ for q_ in params)
+            ok = True
+            for rnd in range(3):
+                for i, p in enumerate(params):
+                    if rnd == 1 and i == 1:
+                        p.grad = None
+                        continue
+                    home = p.__dict__["_locate_grad_buf"]
+                    home.copy_(torch.full_like(p, float(rank + 1 + i + rnd)))
+                    p.grad = home if not (rnd == 2 and i == 0) else home.clone()      # round 2: parameter 0's gradient is elsewhere
+                red.begin()
+                red.finish()
+                for i, p in enumerate(params):
+                    if rnd == 1 and i == 1:
+                        ok = ok and p.grad is None
+                    else:
+                        ok = ok and torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 + i + rnd))
+                at_home = [p.grad is not None and p.grad.data_ptr() == p.__dict__["_locate_grad_buf"].data_ptr() for p in params]
+                ok = ok and at_home == ([True, True, True] if rnd == 0 else ([True, False, True] if rnd == 1 else [False, True, True]))
+                ok = ok and (red._flat[0] is None) and ((red._flat[1] is None) == (rnd < 2))   # a packed copy only for round 2's second bucket
+            q.put((rank, ok, ""))
         elif mode == "disagree":
             red = GradAllReducer(params, bucket_bytes=1 << 20)
             for i, p in enumerate(params):
@@ -157,7 +185,7 @@ def _worker_modes(rank, world, port, mode, q):
         q.put((rank, False, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["avg", "disagree"])
+@pytest.mark.parametrize("mode", ["avg", "homes", "disagree"])
 def test_reducer_modes_world2(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
