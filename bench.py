@@ -69,9 +69,9 @@ def _pmc_traffic(flops_by_stage):
     import hashlib
     try:
         rec = json.load(open(PMC_RECORD))
-        src = os.path.join(ROOT, "locate_amd", "csrc", "conv.hip")
-        if rec.get("conv_hip_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
-            return None, "stale: conv.hip changed since %s was taken" % os.path.relpath(PMC_RECORD, ROOT)
+        srcs = [os.path.join(ROOT, "locate_amd", "csrc", n) for n in ("conv.hip", "convwin.hip", "igemm.h")]
+        if rec.get("conv_hip_sha256") != hashlib.sha256(b"".join(open(x, "rb").read() for x in srcs)).hexdigest():
+            return None, "stale: the contraction kernels' sources changed since %s was taken" % os.path.relpath(PMC_RECORD, ROOT)
         stages = rec["stages"]
         if len(stages) != len(flops_by_stage):
             return None, "record has %d stages, this run %d" % (len(stages), len(flops_by_stage))

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     int bx, by, bz;
-    xcd_tile(bx, by, bz);
+    xcd_tile(bx, by, bz, p.tile_nphase);
     const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
     const int N = p.B * ph.QH * ph.QW;
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
     uint4 (*Bs)[NP][KB][BN] = reinterpret_cast<uint4 (*)[NP][KB][BN]>(smem + A_U4);
 
     int bx, by, bz;
-    xcd_tile(bx, by, bz);
+    xcd_tile(bx, by, bz, p.tile_nphase);
     const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
     const int N = p.B * ph.QH * ph.QW;
@@ -1303,6 +1303,10 @@ void launch_slab_reduce(const IgParams& p, hipStream_t st) {
 }
 
 static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who) {
+    // phase-fastest tile order (xcd_tile) where the output map is large enough for its lines to matter (same-box A/B, gather kernels:
+    // 64x64 maps -5 ... -9 %, 32x32 -3 ... -11 %, 16x16 and 8x8 even; on 4x4 maps the four phases' weight panels thrash the
+    // XCD's L2 instead: +25 %)
+    p.tile_nphase = (path_disabled("phasefast") || (long long)p.OH * p.OW < 1024) ? 1 : p.nphase;
     if (p.win) return launch_win_igemm(p, nmax, slab_ws, counters, st, who);
     if (skinny_ok(p)) {
         p.ksplit = 1;

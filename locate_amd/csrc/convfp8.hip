@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_igemm_fp8_ke
     uint4 (*Bs)[KB][BN] = reinterpret_cast<uint4 (*)[KB][BN]>(smem + A_U4);
 
     int bx, by, bz;
-    xcd_tile(bx, by, bz);
+    xcd_tile(bx, by, bz, p.tile_nphase);
     const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
     const int N = p.B * ph.QH * ph.QW;

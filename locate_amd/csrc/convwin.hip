@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256, 2) conv_win_kernel(const IgParams p) {
     extern __shared__ uint4 smem[];                      // As[2][NP][U][BM] | Bs[2][NP][WINC][SP]; then the epilogue's patches
 
     int bx, by, bz;
-    xcd_tile(bx, by, bz);
+    xcd_tile(bx, by, bz, p.tile_nphase);
     const int zphase = bz / p.ksplit, zsplit = bz - zphase * p.ksplit;
     const IgPhase& ph = p.ph[zphase];
     const int QHW = ph.QH * ph.QW;

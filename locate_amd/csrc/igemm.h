@@ -242,6 +242,7 @@ struct IgParams {
     int lat_z;
     int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
     unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
+    int tile_nphase;     // nphase, or 1: the phase-fastest tile order switched off (debug library, LOCATE_DISABLE=phasefast)
     int win;             // window panel / window kernel (convwin.hip); win_U = chunk rows (units) per stage, win_slotsp = LDS slots
     int win_dbg;         // (debug library: experiment switches of the window kernel)
     int win_U, win_slotsp, win_bm, win_bn;   // per 8-channel window image (largest phase, the zero slot included), win_bm x win_bn = tile
@@ -356,16 +357,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
 // neighbouring tiles - which share a weight-panel slice (same m tile) or a gathered slice (same n tile) - would each
 // fetch it into a different L2.  Remap so that every XCD walks a contiguous chunk of the x-fastest tile order
 // (bijective for any grid size): the co-resident blocks of an XCD then share their operand slices through its L2.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+// nphase > 1 (the sub-pixel phases of a stride-2 adjoint): the PHASE is the fastest index of that order - the 2 x 2 phases of one
+// tile write interleaved pixels of the same output lines (each phase alone leaves every other 4-byte word of a line: half-written
+// lines cost the memory side twice their bytes, profiles/r03_conv_pmc_mem.json: WRITE_SIZE = 2.0 x the output) and gather the same
+// input slice; as neighbours on one XCD their stores meet in its L2 before the lines leave and the slice is fetched once.
+// bz = phase * ksplit + split as before.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int nphase = 1) {
     const int nx = gridDim.x, ny = gridDim.y;
     const int nwg = nx * ny * (int)gridDim.z;
     const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    int phase = 0;
+    if (nphase > 1) { phase = swz % nphase; swz /= nphase; }
     bx = swz % nx;
     const int t = swz / nx;
     by = t % ny;
     bz = t / ny;
+    if (nphase > 1) bz += phase * ((int)gridDim.z / nphase);
 }
 
 // Per-thread state of the implicit-GEMM gather.  The gathered element of (column n, row k = (c, t)) sits at

@@ -95,8 +95,12 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
     fmt = 2 if prec == 2 else 0          # panel format bit: fp16-piece planes
     # window form per direction (R forward gathers x for a conv, gy for a transposed conv)
     in0, in1 = (x, gy) if kind == "conv" else (gy, x)
-    win0 = 4 if (WIN and L.locate_conv_win_ok(garr, 0 | fmt, in0.stride(0), in0.data_ptr())) else 0
-    win1 = 4 if (WIN and L.locate_conv_win_ok(garr, 1 | fmt, in1.stride(0), in1.data_ptr())) else 0
+    # WIN: False = gather kernels, True = the window form wherever it exists, "auto" = where the library recommends it (what the
+    # training step takes: locate_conv_win_ok == 1); never for fp8 / bf16-operand runs of this tool
+    def takes_window(code):
+        return bool(WIN) and prec in (0, 2) and (code == 1 or (code == 2 and WIN is True))
+    win0 = 4 if takes_window(L.locate_conv_win_ok(garr, 0 | fmt, in0.stride(0), in0.data_ptr())) else 0
+    win1 = 4 if takes_window(L.locate_conv_win_ok(garr, 1 | fmt, in1.stride(0), in1.data_ptr())) else 0
     pan0 = torch.empty(max(L.locate_conv_panel_bytes(garr, 0 | fmt | win0), 16), dtype=torch.uint8, device=dev)
     pan1 = torch.empty(max(L.locate_conv_panel_bytes(garr, 1 | fmt | win1), 16), dtype=torch.uint8, device=dev)
     check(L.locate_conv_pack_panel(garr, 0 | fmt | win0, w.data_ptr(), pan0.data_ptr(), S()))
@@ -169,11 +173,12 @@ def main():
     ap.add_argument("--f16", action="store_true", help="fp32-faithful with two scaled fp16 pieces per operand (precision 2)")
     ap.add_argument("--check", action="store_true", help="print the forward / input-gradient error against float64")
     ap.add_argument("--win", action="store_true", help="the window form (csrc/convwin.hip) wherever the geometry has it")
+    ap.add_argument("--win-auto", action="store_true", help="the window form where the library recommends it (what the training step takes)")
     args = ap.parse_args()
     global ZEROS, CHECK, WIN
     ZEROS = args.zeros
     CHECK = args.check
-    WIN = args.win
+    WIN = True if args.win else ("auto" if args.win_auto else False)
     print("%-28s %10s %10s %10s   (ms | TFLOP/s)" % ("stage", "fwd", "dgrad", "wgrad"))
     tot = [0.0, 0.0, 0.0]
     shapes = SHAPES

@@ -14,7 +14,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from locate_amd import Discriminator, Generator, NetConfig, TrainStep, get_model, ops  # noqa: E402
+import tools.bench_conv as bench_conv  # noqa: E402
 from tools.bench_conv import bench_shape  # noqa: E402
+
+bench_conv.WIN = "auto"          # the kernels the step itself takes: the window form where the library recommends it
 
 
 def collect(cfg, batch, dev):

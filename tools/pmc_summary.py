@@ -33,7 +33,8 @@ def per_kernel(path, flt=""):
 def per_dispatch(path, flt, counter):
     """[(kernel, grid, value)] of one counter in dispatch order."""
     f = glob.glob(path + "/**/*counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and flt in r["Kernel_Name"]]
+    flts = flt if isinstance(flt, (tuple, list)) else (flt,)
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and any(x in r["Kernel_Name"] for x in flts)]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [(re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:60], int(r["Grid_Size"]), float(r["Counter_Value"])) for r in rows]
 
@@ -44,9 +45,10 @@ def main():
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
         from tools.roofline_stages import STAGES
-        src = os.path.join(root, "locate_amd", "csrc", "conv.hip")
-        fetch = per_dispatch(fdir, "conv_igemm_bx6_kernel", "FETCH_SIZE")
-        write = per_dispatch(wdir, "conv_igemm_bx6_kernel", "WRITE_SIZE")
+        srcs = [os.path.join(root, "locate_amd", "csrc", n) for n in ("conv.hip", "convwin.hip", "igemm.h")]
+        kernels = ("conv_igemm_bx6_kernel", "conv_win_kernel")          # whichever form each stage takes
+        fetch = per_dispatch(fdir, kernels, "FETCH_SIZE")
+        write = per_dispatch(wdir, kernels, "WRITE_SIZE")
         assert len(fetch) == len(write) and len(fetch) % len(STAGES) == 0, (len(fetch), len(write))
         per = len(fetch) // len(STAGES)                  # launches per stage (reps + 1), in stage order
         batch = 64
@@ -67,7 +69,7 @@ def main():
                              "twice their bytes - on the two launches without split-K (C = 192, 96), whose only stores are the output, "
                              "WRITE_SIZE = 2.000 x output_bytes - while the split-K partial tiles go out as 16-byte stores, which the "
                              "counter reads exactly; hence one output_bytes is subtracted.",
-               "conv_hip_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "stages": stages}
+               "conv_hip_sha256": hashlib.sha256(b"".join(open(x, "rb").read() for x in srcs)).hexdigest(), "stages": stages}
         json.dump(rec, open(out, "w"), indent=1)
         print(json.dumps(rec, indent=1))
         return

@@ -7,6 +7,8 @@ O=gpurun_out/r04; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 30 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err || exit 1
 python bench.py --steps 30 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err || exit 1
+python bench.py --steps 30 --warmup 5 --dtype fp8 --no-cpu-baseline > $O/bench_fp8.json 2> $O/bench_fp8.err || exit 1
+LOCATE_DP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline > $O/dp_world1_rccl.json 2> $O/dp_world1_rccl.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 10 --warmup 2 --step-only > $O/trace.log 2>&1 || exit 1
 python tools/prof_summary.py $O/trace 14 > $O/by_category.txt
 python tools/trace_by_grid.py $O/trace 14 "" 60 > $O/by_kernel_and_grid.txt
@@ -24,6 +26,7 @@ for b in 64 256; do
   python tools/bench_elementwise.py --batch $b > $O/elementwise_microbench_b$b.txt 2>&1
 done
 python tools/bench_conv.py --f16 --check > $O/conv_microbench_f16.txt 2>&1
+python tools/bench_conv.py --f16 --win --check > $O/conv_microbench_f16_window.txt 2>&1
 python tools/bench_conv.py --check > $O/conv_microbench_bf16x6.txt 2>&1
 python tools/layer_table.py > $O/layer_table.txt 2>&1
 python tools/amax_overhead.py > $O/amax_overhead.txt 2>&1
