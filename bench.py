@@ -58,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-PMC_RECORD = os.path.join(ROOT, "profiles", "r03_conv_pmc_mem.json")
+PMC_RECORD = os.path.join(ROOT, "profiles", "r04_conv_pmc_mem.json")
 
 
 def _pmc_traffic(flops_by_stage):
@@ -143,7 +143,7 @@ def conv_roofline(cfg, batch, dev, reps=10, bf16=False, fp8=False):
         kernel = "conv_igemm_bx6_kernel<NP=1> (implicit GEMM, bf16 operands, one bf16 MFMA per 32x32x16 slice, fp32 accumulate, ConvTranspose 4x4 s2 fwd)"
     elif f16:
         kernel = ("conv_igemm_bx6_kernel<NP=2> (implicit GEMM, fp32-faithful: 2 x fp16 scaled operand pieces, 3 fp16 MFMAs per 32x32x16 "
-                  "slice, ConvTranspose 4x4 s2 fwd)")
+                  "slice, ConvTranspose 4x4 s2 fwd; the weight-streaming stage C = 768 through the window form conv_win_kernel<NP=2>)")
     else:
         kernel = ("conv_igemm_bx6_kernel<NP=3> (implicit GEMM, 3 x bf16 exact operand splits, 6 bf16 MFMAs per 32x32x16 slice, "
                   "ConvTranspose 4x4 s2 fwd)")

@@ -2149,9 +2149,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
                                       // swapped on rows with bit 3 set, which makes both the ds_read_b128 fragment reads
                                       // (16-lane groups = 16 consecutive rows) and the dword writes conflict-free
 
-// NP = 4: fp8 operands (BASELINE configs[4]) - both operands scaled into e4m3's range and rounded to e4m3 (v_cvt_pk_fp8_f32, the
-// arithmetic of convfp8.hip), then fed to the bf16 MFMA, in which every e4m3 value is exact: the products and the fp32 accumulation
-// are those of an fp8 MFMA, on this kernel's bf16 LDS images (the reduction index n needs pairs, which the 16-bit layout provides).
+// NP = 4: fp8 operands (BASELINE configs[4], the arithmetic of convfp8.hip): both operands scaled into e4m3's range, rounded to e4m3
+// (v_cvt_pk_fp8_f32, a pair per instruction) and multiplied on v_mfma_f32_32x32x16_fp8_fp8.  LDS rows are 16 bytes (16 consecutive
+// n of one row / column); lane (r, h) reads the 8 bytes k = 8h .. 8h + 7, the two halves swapped on rows with bit 4 set (conflict-free
+// ds_read_b64 over 32 rows); a thread's pair goes in as one 16-bit store.
 template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands; NP = 2: two scaled fp16 pieces (see conv_igemm_bx6_kernel)
 __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
@@ -2161,8 +2162,10 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     static_assert(WGM * WGN == 4, "four waves");
 
     constexpr int NPL = NP == 4 ? 1 : NP;          // piece planes in LDS
-    __shared__ unsigned Gs[2][NPL][BM][WB_PITCH];
-    __shared__ unsigned Xs[2][NPL][BR][WB_PITCH];
+    __shared__ unsigned Gs[2][NPL][NP == 4 ? 1 : BM][WB_PITCH];
+    __shared__ unsigned Xs[2][NPL][NP == 4 ? 1 : BR][WB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short G8[2][NP == 4 ? BM : 1][8];          // fp8: 16 bytes per row, addressed in pairs
+    __shared__ __attribute__((aligned(16))) unsigned short X8[2][NP == 4 ? BR : 1][8];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -2230,13 +2233,10 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
         g_scale = pow2f(kg_); g_unscale = pow2f(-kg_);
         x_scale = pow2f(kx_); x_unscale = pow2f(-kx_);
     }
-    // a pair of values rounded to e4m3 and back (exact in bf16), packed as bf16
-    auto q8_pair = [](float v0, float v1) {
-        const int t = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(t, false);
-        return round_bf16_pair(r[0], r[1]);
-    };
+    // a pair of values rounded to e4m3: two bytes
+    auto q8_pair = [](float v0, float v1) { return (unsigned short)(__builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false) & 0xffff); };
+    // pair np of a row: halfword (np & 3) of the row's 8-byte half np >> 2, the halves swapped on rows with bit 4 set
+    auto h8 = [](int row, int pair) { return ((((pair >> 2) ^ (row >> 4)) & 1) << 2) | (pair & 3); };
 
     float2 greg[G_PT], xreg[X_PT];
     auto load_tiles = [&](int nb) {
@@ -2290,7 +2290,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
                 Gs[buf][NP - 2][sub + 32 * i][wcol] = m;
                 Gs[buf][NP - 1][sub + 32 * i][wcol] = l;
             } else if constexpr (NP == 4) {
-                Gs[buf][0][sub + 32 * i][wcol] = q8_pair(greg[i].x * gsc * g_scale, greg[i].y * gsc * g_scale);
+                G8[buf][sub + 32 * i][h8(sub + 32 * i, np)] = q8_pair(greg[i].x * gsc * g_scale, greg[i].y * gsc * g_scale);
             } else {
                 Gs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(greg[i].x * gsc, greg[i].y * gsc);
             }
@@ -2309,7 +2309,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
                 Xs[buf][NP - 2][sub + 32 * i][wcol] = m;
                 Xs[buf][NP - 1][sub + 32 * i][wcol] = l;
             } else if constexpr (NP == 4) {
-                Xs[buf][0][sub + 32 * i][wcol] = q8_pair(xreg[i].x * x_scale, xreg[i].y * x_scale);
+                X8[buf][sub + 32 * i][h8(sub + 32 * i, np)] = q8_pair(xreg[i].x * x_scale, xreg[i].y * x_scale);
             } else {
                 Xs[buf][0][sub + 32 * i][wcol] = round_bf16_pair(xreg[i].x, xreg[i].y);
             }
@@ -2333,14 +2333,23 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         frag_t a[TM][NPL], b[TN][NPL];
+        long a8[TM], b8[TN];
+        if constexpr (NP == 4) {
+            const int half8 = (lrow ^ (lcol >> 4)) & 1;          // (tile rows start at multiples of 32: bit 4 of the row = bit 4 of lcol)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const long*>(&G8[buf][(wm * TM + i) * 32 + lcol][half8 * 4]);
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
+            for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const long*>(&X8[buf][(wn * TN + j) * 32 + lcol][half8 * 4]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+                for (int q = 0; q < NPL; ++q) a[i][q] = *reinterpret_cast<const frag_t*>(&Gs[buf][q][(wm * TM + i) * 32 + lcol][rhalf * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) b[j][q] = *reinterpret_cast<const frag_t*>(&Xs[buf][q][(wn * TN + j) * 32 + lcol][rhalf * 4]);
+        }
         auto mfmas = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -2358,6 +2367,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
                         if (base + 3 >= lo && base + 3 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][0], acc[i][j], 0, 0, 0);   // m h
                         if (base + 4 >= lo && base + 4 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 2], acc[i][j], 0, 0, 0);   // h m
                         if (base + 5 >= lo && base + 5 < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);   // h h
+                    } else if constexpr (NP == 4) {
+                        if (base >= lo && base < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8[i], b8[j], acc[i][j], 0, 0, 0);
                     } else {
                         if (base >= lo && base < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                     }

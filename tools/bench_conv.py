@@ -156,7 +156,7 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
             float((y.double().cpu() - yr).abs().max() / yr.abs().max()), float((gx.double().cpu() - gr).abs().max() / gr.abs().max()),
             float((gw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())))
     if WIN:
-        print("    window form: R forward %s, R adjoint %s" % (bool(win0), bool(win1)))
+        print("    window form: R forward %s, R adjoint %s" % (bool(win0), bool(win1)), file=sys.stderr)
     ms = [time_it(f, reps) for f in (fwd, dgr, wgr)]
     nbytes = 4.0 * (x.numel() + y.numel()) + 6.0 * w.numel()      # activations once each + the three bf16 weight planes
     return ms, flops, nbytes

@@ -61,14 +61,14 @@ def main():
             out_bytes = 4 * batch * c * (2 * size) ** 2
             stages.append({"C": c, "in": size, "kernel": fs[0][0], "grid_threads": fs[0][1], "dispatches": per,
                            "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1), "output_bytes": out_bytes,
-                           "hbm_bytes_per_launch": int(2.0 * f_kib * 1024 + w_kib * 1024 - out_bytes)})
+                           "hbm_bytes_per_launch": int(2.0 * f_kib * 1024 + w_kib * 1024)})
         rec = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python3 tools/roofline_stages.py --reps 5",
-               "correction": "HBM-side bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE - output_bytes.  FETCH_SIZE doubled: gfx950 tallies a "
-                             "128-byte read request as 64 bytes (MI355X_MICROARCH.md, HBM).  WRITE_SIZE calibrated on this kernel's own "
-                             "store shape: the epilogue's 4-byte-per-lane stores (128 contiguous bytes per 32 lanes) are tallied at exactly "
-                             "twice their bytes - on the two launches without split-K (C = 192, 96), whose only stores are the output, "
-                             "WRITE_SIZE = 2.000 x output_bytes - while the split-K partial tiles go out as 16-byte stores, which the "
-                             "counter reads exactly; hence one output_bytes is subtracted.",
+               "correction": "HBM-side bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE.  FETCH_SIZE doubled: gfx950 tallies a 128-byte read "
+                             "request as 64 bytes (MI355X_MICROARCH.md, HBM).  WRITE_SIZE as counted: round 3 read the un-split stages' "
+                             "WRITE_SIZE = 2.000 x output bytes as a tally artefact of 4-byte-per-lane stores and subtracted one output; "
+                             "round 4 shows it was REAL traffic - each sub-pixel phase wrote every other word of a line - because the same "
+                             "stores count ~1.0 x the output once the four phases of a tile run as neighbours on one XCD (phase-fastest "
+                             "tile order, igemm.h xcd_tile) and their stores meet in its L2.",
                "conv_hip_sha256": hashlib.sha256(b"".join(open(x, "rb").read() for x in srcs)).hexdigest(), "stages": stages}
         json.dump(rec, open(out, "w"), indent=1)
         print(json.dumps(rec, indent=1))
