@@ -369,12 +369,16 @@ def main():
         red_g.timing = red_d.timing = False
         comm = {"buckets_sent": {"D": {"in_place": red_d.sent_in_place, "packed": red_d.sent_packed},
                                  "G": {"in_place": red_g.sent_in_place, "packed": red_g.sent_packed}},
+                "collectives": {"D": red_d.collectives, "G": red_g.collectives},
                 "allreduce_ms_per_step": {"D": round(td / 5, 4), "G": round(tg / 5, 4)},
                 "exposed_ms_per_step": {"D": round(xd / 5, 4), "G": round(xg / 5, 4)},
                 "payload_MB": {"D": round(sum(p.numel() for p in D.parameters()) * 4 / 1e6, 1),
                                "G": round(sum(p.numel() for p in G.parameters()) * 4 / 1e6, 1)},
-                "note": "side-stream time of pack + RCCL all-reduce + unpack per optimizer step, and the part of it the compute "
-                        "stream had to wait for; D's deep segment (blocks 3.. + head, ~95 % of its parameters) is sent while "
+                "note": "buckets_sent / collectives: counts over the whole run (eager warm-up included; a replayed step sends a "
+                        "backward segment's resident buckets as ONE collective, handed to the process group from the compute stream). "
+                        "allreduce_ms: from the hand-over to the compute stream's join (an upper bound of the exchange: the overlapped "
+                        "segment is inside) - for packed buckets the side stream's pack + all-reduce + unpack; exposed_ms: what "
+                        "the compute stream waited at the join; D's deep segment (blocks 3.. + head, ~95 % of its parameters) is sent while "
                         "the high-resolution segment's backward runs, G's widest layers are the last its backward produces"}
     if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

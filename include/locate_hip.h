@@ -195,11 +195,17 @@ size_t locate_conv_counter_bytes(void);
 int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* panel, const float* scale,
                     int scale_group_batch, int scale_stride, const float* bias, float* y, int64_t y_bs, void* workspace,
                     void* counters, int precision, const void* x_absmax, const void* act_epilogue, void* stream);
-/* act_epilogue (nullable; layers on 1x1 maps only - style linears, the channel gate's squeeze convs): HOST pointer to
- *   struct { void* act_out; int64_t act_bs; const void* lat; int64_t lat_bs; int32_t lat_z, pad; }
- * the launch also writes act_out[n * act_bs + j] = RootTanh(y[n, j]) (libs/linear.py:12-13, libs/attention.py:26,31) and, with
- * lat, copies lat[n, 0 .. lat_z) in front of it (act_out[n * act_bs - lat_z ..]): the next style link's input
- * cat([latent, activated]) (libs/block.py:119-125) in the same launch */
+/* act_epilogue (nullable): HOST pointer to
+ *   struct { void* act_out; int64_t act_bs; const void* lat; int64_t lat_bs; int32_t lat_z, pad;
+ *            const void* mul_pre; int64_t mul_bs; void* out_absmax; }
+ * act_out: the launch also writes act_out[b, m, pixel] = RootTanh(y[b, m, pixel]) (batch stride act_bs elements) - the
+ *   activation between the two convs of a stage (libs/conv.py:19-20, libs/attention.py:44-46, libs/linear.py:12-13) without a
+ *   launch and a read of its own; on 1x1 maps, with lat, it copies lat[n, 0 .. lat_z) in front of row n
+ *   (act_out[n * act_bs - lat_z ..]): the next style link's input cat([latent, activated]) (libs/block.py:119-125).
+ * mul_pre (locate_conv_dgrad; excludes act_out): the contraction's result is multiplied by RootTanh'(mul_pre[b, c, pixel])
+ *   (batch stride mul_bs) before it is stored - the input gradient of a conv whose input was RootTanh(mul_pre) leaves the launch
+ *   as the gradient of mul_pre itself (the separate locate_roottanh_bwd launch and its read of gx disappear).
+ * out_absmax (nullable): locate_absmax_words() zeroed words that receive the largest magnitude of act_out (of gx with mul_pre). */
 /* precision: 0 = fp32-faithful with three bf16 pieces per operand (six bf16 MFMAs per 32x32x16 slice); 1 = operands rounded
  * to bf16 (one MFMA); 2 = fp32-faithful with TWO fp16 pieces per operand (three fp16 MFMAs): both operands are scaled by a
  * power of two into fp16's range - the weights when the panel is packed (panel format bit: `adjoint | 2` in
@@ -211,7 +217,7 @@ int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, const float* 
 size_t locate_conv_dgrad_workspace_bytes(const int* geom);
 int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                       int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs, void* workspace,
-                      void* counters, int precision, const void* gy_absmax, void* stream);
+                      void* counters, int precision, const void* gy_absmax, const void* act_epilogue, void* stream);
 /* gw[m,c,kh,kw] = inv_scale * sum_{b,oh,ow} gy[b,m,oh,ow] x[b,c,oh*s-ph+kh,ow*s-pw+kw] (deterministic split reduction).
  * With w_ref (= W_bar) and inner_partial the same pass emits locate_conv_wgrad_partials(geom) partial sums (double)
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.

@@ -86,7 +86,7 @@ PROTOTYPES = {
     "locate_conv_counter_bytes": (c_sz, []),
     "locate_conv_fwd": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p, c_p]),
     "locate_conv_dgrad_workspace_bytes": (c_sz, [c_ip]),
-    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p]),
+    "locate_conv_dgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_i, c_p, c_p, c_p]),
     "locate_conv_wgrad_workspace_bytes": (c_sz, [c_ip]),
     "locate_conv_wgrad_partials": (c_i, [c_ip]),
     "locate_conv_wgrad": (c_i, [c_ip, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
@@ -130,7 +130,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 8
+EXPECTED_ABI = 9
 
 
 _lib = None

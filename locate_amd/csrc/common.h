@@ -84,6 +84,17 @@ __device__ __forceinline__ void absmax_publish(float m, float* scratch, unsigned
             (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // result unused: no return trip
     }
 }
+// the same from a kernel whose waves finish on their own (the contractions' fused epilogues): one atomic per wave, no block barrier
+__device__ __forceinline__ void absmax_publish_wave(float m, unsigned* slot) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned lin = blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (threadIdx.x >> 6) * 5u;
+        unsigned* word = slot + AMAX_STRIDE * (lin & (AMAX_LINES - 1));
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // the consumer's side: maximum of the AMAX_LINES words (wave-uniform)
 __device__ __forceinline__ unsigned absmax_read(const unsigned* slot) {
     unsigned v = slot[AMAX_STRIDE * (threadIdx.x & (AMAX_LINES - 1))];
@@ -137,25 +148,33 @@ struct DivU32 {
 // These kernels are ALU-bound with libm's expm1f / IEEE sqrt and division (~75 instructions per element against 8-12
 // bytes of traffic), so they use the hardware approximations (v_exp_f32, v_rcp_f32, v_sqrt_f32: 1 ulp each) and a short
 // series where exp(t) - 1 would cancel: ~30 instructions, errors of a few 1e-7 relative (tests: 2e-6 against fp64).
+// Every operation is spelled out (fmaf / __fmul_rn / __fadd_rn): with the compiler free to contract a * b + c its own way per
+// call site, the same formula inlined into two kernels (an element-wise launch, a contraction's fused epilogue) rounds
+// differently - and the fused and the separate form of an activation are held to the same bits (tests/test_gpu_ops.py).
 __device__ __forceinline__ float expm1_nonpos(float t) {          // t <= 0
-    const float series = t * (1.0f + t * (0.5f + t * (0.16666667f + t * (0.041666668f + t * (0.0083333338f +
-                         t * (0.0013888889f + t * 0.0001984127f))))));          // |t| <= 0.35: truncation < 2e-8 |t|
-    const float direct = __builtin_amdgcn_exp2f(t * 1.44269504f) - 1.0f;
+    float s = fmaf(t, 0.0001984127f, 0.0013888889f);
+    s = fmaf(t, s, 0.0083333338f);
+    s = fmaf(t, s, 0.041666668f);
+    s = fmaf(t, s, 0.16666667f);
+    s = fmaf(t, s, 0.5f);
+    s = fmaf(t, s, 1.0f);
+    const float series = __fmul_rn(t, s);          // |t| <= 0.35: truncation < 2e-8 |t|
+    const float direct = __fsub_rn(__builtin_amdgcn_exp2f(__fmul_rn(t, 1.44269504f)), 1.0f);
     return t > -0.35f ? series : direct;
 }
 
 __device__ __forceinline__ void tanh_sech2(float x, float& th, float& sech2) {
     const float ax = fabsf(x);
-    const float em = expm1_nonpos(-2.0f * ax);
-    const float r = __builtin_amdgcn_rcpf(2.0f + em);
-    th = copysignf(-em * r, x);
-    sech2 = 4.0f * (1.0f + em) * r * r;
+    const float em = expm1_nonpos(__fmul_rn(-2.0f, ax));
+    const float r = __builtin_amdgcn_rcpf(__fadd_rn(2.0f, em));
+    th = copysignf(__fmul_rn(-em, r), x);
+    sech2 = __fmul_rn(__fmul_rn(__fmul_rn(4.0f, __fadd_rn(1.0f, em)), r), r);
 }
 
 __device__ __forceinline__ float roottanh_f(float x) {
     float th, s2;
     tanh_sech2(x, th, s2);
-    return __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(fmaf(x, x, 1.0f))) * th;
+    return __fmul_rn(__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(fmaf(x, x, 1.0f))), th);
 }
 
 __device__ __forceinline__ float roottanh_grad_f(float x, float g) {
@@ -163,8 +182,9 @@ __device__ __forceinline__ float roottanh_grad_f(float x, float g) {
     tanh_sech2(x, th, s2);
     const float q = fmaf(x, x, 1.0f);
     const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(q));          // q^(1/4)
-    const float q34 = r * r * r;              // q^(3/4)
-    return g * (2.0f * q * s2 + x * th) * (0.5f * __builtin_amdgcn_rcpf(q34));
+    const float q34 = __fmul_rn(__fmul_rn(r, r), r);              // q^(3/4)
+    const float inner = fmaf(x, th, __fmul_rn(__fmul_rn(2.0f, q), s2));
+    return __fmul_rn(__fmul_rn(g, inner), __fmul_rn(0.5f, __builtin_amdgcn_rcpf(q34)));
 }
 
 #endif

@@ -1003,12 +1003,16 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : 3)
 __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 int scale_bg, int scale_stride, int B, int M, int plane,
-                                                                long long out_bs, long long slab_stride, int ksplit) {
+                                                                long long out_bs, long long slab_stride, int ksplit,
+                                                                float* __restrict__ act_out, long long act_bs,
+                                                                const float* __restrict__ mul_pre, long long mul_bs,
+                                                                unsigned* __restrict__ out_absmax) {
     // flat indices stay below 2^31 (host entry): power-of-two shifts or one 32-bit division instead of 64-bit ones
     const unsigned per_b = (unsigned)M * (unsigned)plane;
     const unsigned total = (unsigned)B * per_b;
     const unsigned stride = gridDim.x * blockDim.x;
     const DivU32 dpb(per_b), dpl((unsigned)plane);
+    float am = 0.0f;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         unsigned b, r;
         dpb.divmod(i, b, r);
@@ -1032,8 +1036,12 @@ __global__ void __launch_bounds__(256) igemm_slab_reduce_kernel(const float* __r
         }
         if (scale) acc *= scale[(scale_bg ? (int)b / scale_bg : 0) * scale_stride];
         if (bias) acc += bias[dpl.div(r)];
+        // the fused forms of igemm_epilogue (IgParams::act_out / mul_pre)
+        if (mul_pre) { acc = roottanh_grad_f(mul_pre[(long long)b * mul_bs + r], acc); am = fmaxf(am, fabsf(acc)); }
         out[(long long)b * out_bs + r] = acc;
+        if (act_out) { const float a = roottanh_f(acc); act_out[(long long)b * act_bs + r] = a; am = fmaxf(am, fabsf(a)); }
     }
+    if (out_absmax) absmax_publish_wave(am, out_absmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1048,8 +1056,9 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     const IgPhase& ph = p.ph[0];
     const int HW = p.H * p.W;
     const long long npx = (long long)p.B * HW / PX;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npx) return;
+    const long long i_ = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i_ < npx;          // (no early return: the fused epilogue's largest-magnitude word is a wave reduction)
+    const long long i = live ? i_ : 0;
     const long long n = PX * i;
     const int b = (int)(n / HW), q = (int)(n - (long long)b * HW);
     const float* ip = p.in + (long long)b * p.in_bs + q;
@@ -1086,15 +1095,45 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const IgParams p) {
     }
     const float sc = p.scale ? p.scale[(p.scale_bg ? b / p.scale_bg : 0) * p.scale_stride] : 1.0f;
     float* op = p.out + (long long)b * p.out_bs + q;
+    if (p.act_out == nullptr && p.mul_pre == nullptr) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < p.M && live) {
+                const float bv = p.bias ? p.bias[m] : 0.0f;
+                const float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
+                if (PX == 2) *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(v0, v1);
+                else op[(long long)m * HW] = v0;
+            }
+        }
+        return;
+    }
+    // the fused forms of igemm_epilogue (IgParams::act_out / mul_pre); pointwise_ok has checked their alignment
+    float am = 0.0f;
+    const float* zp = p.mul_pre ? p.mul_pre + (long long)b * p.mul_bs + q : nullptr;
+    float* ap = p.act_out ? p.act_out + (long long)b * p.act_bs + q : nullptr;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m < p.M) {
+        if (m < p.M && live) {
             const float bv = p.bias ? p.bias[m] : 0.0f;
-            const float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
+            float v0 = fmaf(acc[m][0], sc, bv), v1 = fmaf(acc[m][PX - 1], sc, bv);
+            if (zp) {
+                float z0, z1;
+                if (PX == 2) { const float2 t = *reinterpret_cast<const float2*>(zp + (long long)m * HW); z0 = t.x; z1 = t.y; }
+                else { z0 = zp[(long long)m * HW]; z1 = z0; }
+                v0 = roottanh_grad_f(z0, v0); v1 = roottanh_grad_f(z1, v1);
+                am = fmaxf(am, fmaxf(fabsf(v0), fabsf(v1)));
+            }
             if (PX == 2) *reinterpret_cast<float2*>(op + (long long)m * HW) = make_float2(v0, v1);
             else op[(long long)m * HW] = v0;
+            if (ap) {
+                const float a0 = roottanh_f(v0), a1 = roottanh_f(v1);
+                if (PX == 2) *reinterpret_cast<float2*>(ap + (long long)m * HW) = make_float2(a0, a1);
+                else ap[(long long)m * HW] = a0;
+                am = fmaxf(am, fmaxf(fabsf(a0), fabsf(a1)));
+            }
         }
     }
+    if (p.out_absmax) absmax_publish_wave(am, p.out_absmax);
 }
 
 
@@ -1169,15 +1208,18 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_rows_kernel(const IgPara
     // wave t finishes row t of the tile: the partial sums in wave order, then scale and bias
     if (wid < SK_NT) {
         const int n = n0 + wid;
+        float am = 0.0f;
         if (n < N && j < J) {
             float s = red[0][wid][lane];
 #pragma unroll
             for (int w = 1; w < SK_WAVES; ++w) s += red[w][wid][lane];
             const float sc = p.scale ? p.scale[(p.scale_bg ? n / p.scale_bg : 0) * p.scale_stride] : 1.0f;
-            const float v = fmaf(s, sc, p.bias ? p.bias[j] : 0.0f);
+            float v = fmaf(s, sc, p.bias ? p.bias[j] : 0.0f);
+            if (p.mul_pre) { v = roottanh_grad_f(p.mul_pre[(long long)n * p.mul_bs + j], v); am = fabsf(v); }
             p.out[(long long)n * p.out_bs + j] = v;
-            if (p.act_out) p.act_out[(long long)n * p.act_bs + j] = roottanh_f(v);
+            if (p.act_out) { const float a = roottanh_f(v); p.act_out[(long long)n * p.act_bs + j] = a; am = fabsf(a); }
         }
+        if (p.out_absmax) absmax_publish_wave(am, p.out_absmax);
         if (p.lat && blockIdx.x == 0 && n < N)          // the latent columns of the next link's input row n
             for (int c = lane; c < p.lat_z; c += 64) p.act_out[(long long)n * p.act_bs - p.lat_z + c] = p.lat[(long long)n * p.lat_bs + c];
     }
@@ -1200,7 +1242,9 @@ static bool pointwise_ok(const IgParams& p) {
     return ph.T == 1 && p.istride == 1 && p.ostep == 1 && ph.dy0 == 0 && ph.dx0 == 0 && p.H == p.OH && p.W == p.OW &&
            ph.K >= 1 && ph.K <= 64 && p.M <= 64 && ph.ld >= ((p.M + 15) / 16) * 16 && (HW & 1) == 0 && (p.in_bs & 1) == 0 &&
            (p.out_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(p.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 7) == 0 &&
-           (long long)p.B * HW >= 131072;
+           (long long)p.B * HW >= 131072 &&
+           (!p.act_out || ((p.act_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(p.act_out) & 7) == 0)) &&
+           (!p.mul_pre || ((p.mul_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(p.mul_pre) & 7) == 0));
 }
 
 template <int PX>
@@ -1299,7 +1343,7 @@ static SplitPlan igemm_split_plan(const IgParams& p, int nmax, bool have_counter
 
 void launch_slab_reduce(const IgParams& p, hipStream_t st) {
     igemm_slab_reduce_kernel<<<stream_grid(p.slab_stride, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW,
-                                                                              p.out_bs, p.slab_stride, p.ksplit);
+                                                                              p.out_bs, p.slab_stride, p.ksplit, p.act_out, p.act_bs, p.mul_pre, p.mul_bs, p.out_absmax);
 }
 
 static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters, hipStream_t st, const char* who) {
@@ -1383,8 +1427,7 @@ static int launch_igemm(IgParams& p, int nmax, void* slab_ws, unsigned* counters
     if (p.ksplit > 1 && !p.combine) {
         const long long total = p.slab_stride;
         LOCATE_REQUIRE(total < (1ll << 31), "%s: split-K output of %lld elements exceeds the 32-bit index range", who, total);
-        igemm_slab_reduce_kernel<<<stream_grid(total, 256), 256, 0, st>>>(p.slab, p.out, p.bias, p.scale, p.scale_bg, p.scale_stride, p.B, p.M, p.OH * p.OW, p.out_bs,
-                                                                         p.slab_stride, p.ksplit);
+        launch_slab_reduce(p, st);
         LOCATE_LAUNCH_CHECK(who);
     }
     return LOCATE_OK;
@@ -1795,6 +1838,9 @@ struct LocateActEpilogue {
     const void* lat;
     long long lat_bs;
     int lat_z, pad;
+    const void* mul_pre;
+    long long mul_bs;
+    void* out_absmax;
 };
 
 static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in_bs, const float* panel, const float* scale,
@@ -1809,11 +1855,11 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
     p.precision = precision;
     p.b_absmax = in_absmax;
     p.act_out = nullptr; p.act_bs = 0; p.lat = nullptr; p.lat_bs = 0; p.lat_z = 0;
+    p.mul_pre = nullptr; p.mul_bs = 0; p.out_absmax = nullptr;
     int nmax = 0;
     if (int e = conv_plan(g, (adjoint & 1) | (win ? 4 : 0) | (precision == 2 ? 2 : 0) | (precision == 3 ? 8 : 0), nullptr, const_cast<float*>(panel), p, &nmax, nullptr, false, st)) return e;
     LOCATE_REQUIRE(p.nphase > 0, "%s: empty output", who);
     LOCATE_REQUIRE(!win || ((in_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0), "%s: the window form loads pixel pairs: 8-byte aligned tensor, even batch stride", who);
-    LOCATE_REQUIRE(!win || !(epi && epi->act_out), "%s: no activated second output in the window form", who);
     p.in = in; p.out = out; p.bias = bias; p.scale = scale; p.in_bs = in_bs; p.out_bs = out_bs;
     p.scale_bg = scale_bg; p.scale_stride = scale_stride;
     {
@@ -1824,11 +1870,18 @@ static int run_igemm(const ConvGeom& g, int adjoint, const float* in, int64_t in
     LOCATE_REQUIRE(scale_bg >= 0 && (scale_bg == 0 || g.B % scale_bg == 0), "%s: batch %d is not a multiple of the scale group %d", who, g.B, scale_bg);
     LOCATE_REQUIRE(ws || slab_floats(p, nmax) == 0, "%s: split-K needs a workspace", who);
     if (epi && epi->act_out) {
-        LOCATE_REQUIRE(skinny_ok(p), "%s: the activated second output exists for 1x1-map layers only", who);
+        LOCATE_REQUIRE(!epi->lat || skinny_ok(p), "%s: the latent prefix of the activated second output exists for 1x1-map layers only", who);
         LOCATE_REQUIRE(!epi->lat || (epi->lat_z > 0 && epi->act_bs >= epi->lat_z + g.M), "%s: bad latent prefix", who);
+        LOCATE_REQUIRE(!epi->mul_pre, "%s: an epilogue either activates or multiplies by the activation's derivative", who);
+        LOCATE_REQUIRE(epi->act_bs >= (long long)p.M * p.OH * p.OW, "%s: activated output's batch stride is smaller than one element of the batch", who);
         p.act_out = static_cast<float*>(epi->act_out); p.act_bs = epi->act_bs;
         p.lat = static_cast<const float*>(epi->lat); p.lat_bs = epi->lat_bs; p.lat_z = epi->lat ? epi->lat_z : 0;
     }
+    if (epi && epi->mul_pre) {
+        LOCATE_REQUIRE(epi->mul_bs >= (long long)p.M * p.OH * p.OW, "%s: pre-activation's batch stride is smaller than one element of the batch", who);
+        p.mul_pre = static_cast<const float*>(epi->mul_pre); p.mul_bs = epi->mul_bs;
+    }
+    if (epi && (epi->act_out || epi->mul_pre)) p.out_absmax = static_cast<unsigned*>(epi->out_absmax);
     return launch_igemm(p, nmax, ws, counters, st, who);
 }
 
@@ -1909,13 +1962,14 @@ LOCATE_API int locate_conv_fwd(const int* geom, const float* x, int64_t x_bs, co
 // Every element of gx [B, C, H, W] is written.
 LOCATE_API int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const float* panel, const float* scale,
                                  int scale_group_batch, int scale_stride, const float* bias, float* gx, int64_t gx_bs,
-                                 void* workspace, void* counters, int precision, const void* gy_absmax, void* stream) {
+                                 void* workspace, void* counters, int precision, const void* gy_absmax, const void* act_epilogue,
+                                 void* stream) {
     const ConvGeom g = make_geom(geom);
     if (int e = geom_check(g, "locate_conv_dgrad")) return e;
     LOCATE_REQUIRE(gy && panel && gx, "locate_conv_dgrad: null pointer");
     return run_igemm(g, 1, gy, gy_bs, panel, scale, scale_group_batch, scale_stride, bias, gx, gx_bs,
                      static_cast<float*>(workspace), static_cast<unsigned*>(counters), precision, static_cast<const unsigned*>(gy_absmax),
-                     as_stream(stream), "locate_conv_dgrad");
+                     as_stream(stream), "locate_conv_dgrad", static_cast<const LocateActEpilogue*>(act_epilogue));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -235,11 +235,21 @@ struct IgParams {
     // activated second output (1x1-map layers, skinny_rows_kernel only): act_out[n, j] = RootTanh(out[n, j]) with its own row
     // stride, and - a style-chain link writing the NEXT link's input [latent | activation] (libs/block.py:119-125) - the
     // lat_z latent columns copied in front of it: act_out - lat_z is then the start of that row
-    float* act_out;
-    long long act_bs;
-    const float* lat;
-    long long lat_bs;
-    int lat_z;
+    // On any other map (no latent): act_out[b, m, pixel] = RootTanh(out[b, m, pixel]), batch stride act_bs (igemm_epilogue,
+    // conv_pointwise_kernel, igemm_slab_reduce_kernel) - the activation between the two convs of a stage, without a launch and
+    // a read of its own.
+    float* act_out = nullptr;
+    long long act_bs = 0;
+    const float* lat = nullptr;
+    long long lat_bs = 0;
+    int lat_z = 0;
+    // The mirror image for an input-gradient launch whose input tensor WAS such an activation a = RootTanh(pre): the epilogue
+    // multiplies by RootTanh'(pre) - out[b, c, pixel] = roottanh_grad(mul_pre[b, c, pixel], contraction) - so what leaves the launch
+    // is the gradient of `pre` (batch stride mul_bs).
+    const float* mul_pre = nullptr;
+    long long mul_bs = 0;
+    // AMAX_WORDS words (zero before the launch) that receive the largest magnitude of act_out (or, with mul_pre, of out)
+    unsigned* out_absmax = nullptr;
     int combine;         //   combine == 1: [ksplit][tile][fragment][thread][4] (every store / load instruction of the block is
     unsigned* counters;  //   one contiguous KiB), summed INSIDE this launch by the tile's last-arriving block (counters[tile])
     int tile_nphase;     // nphase, or 1: the phase-fastest tile order switched off (debug library, LOCATE_DISABLE=phasefast)
@@ -280,6 +290,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
     if (stage != nullptr && p.nphase == 1 && p.ostep == 1 && iplane <= 16 && (iplane & (iplane - 1)) == 0 &&
         ph.QH * ph.QW == iplane) {
         const int lp = __ffs(iplane) - 1;
+        const bool fused_s = !split && (p.act_out != nullptr || p.mul_pre != nullptr);
+        float am_s = 0.0f;
         float* out_base = split ? p.slab + (long long)zsplit * p.slab_stride : p.out;
         const long long obs = split ? (long long)p.M * plane : p.out_bs;
 #pragma unroll
@@ -303,21 +315,49 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 const int b0 = nt0 >> lp;
+                if (!fused_s) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int flat = e * 64 + lane;
-                    const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
-                    const int ml = rem >> lp, pix = rem & (iplane - 1);
-                    const int nl = (bl << lp) + pix;
-                    const float v = stage[nl * 33 + ml];
-                    if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int flat = e * 64 + lane;
+                        const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
+                        const int ml = rem >> lp, pix = rem & (iplane - 1);
+                        const int nl = (bl << lp) + pix;
+                        const float v = stage[nl * 33 + ml];
+                        if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
+                    }
+                } else {
+                    // the fused forms (see below): a rolled loop - the values come from the LDS patch, not from the accumulators
+#pragma unroll 1
+                    for (int e = 0; e < 16; ++e) {
+                        const int flat = e * 64 + lane;
+                        const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
+                        const int ml = rem >> lp, pix = rem & (iplane - 1);
+                        const int nl = (bl << lp) + pix;
+                        float v = stage[nl * 33 + ml];
+                        if (nt0 + nl < N && mt0 + ml < p.M) {
+                            const long long rel = (long long)(mt0 + ml) * plane + pix;
+                            if (p.mul_pre != nullptr) {
+                                v = roottanh_grad_f(p.mul_pre[(long long)(b0 + bl) * p.mul_bs + rel], v);
+                                am_s = fmaxf(am_s, fabsf(v));
+                            }
+                            out_base[(long long)(b0 + bl) * obs + rel] = v;
+                            if (p.mul_pre == nullptr) {
+                                const float a = roottanh_f(v);
+                                p.act_out[(long long)(b0 + bl) * p.act_bs + rel] = a;
+                                am_s = fmaxf(am_s, fabsf(a));
+                            }
+                        }
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
         }
+        if (fused_s && p.out_absmax != nullptr) absmax_publish_wave(am_s, p.out_absmax);
         return;
     }
     const float* optr[TN];         // per column tile: address of (row 0, this lane's column); null beyond N
+    long long xoff[TN];            // fused forms: offset of the same element in act_out / mul_pre relative to its offset in out
+    const bool fused = !split && (p.act_out != nullptr || p.mul_pre != nullptr);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nj = n0 + (wn * TN + j) * 32 + lcol;
@@ -329,7 +369,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
         const float* o = split ? p.slab + (long long)zsplit * p.slab_stride + (long long)b * p.M * plane + pix
                                : p.out + (long long)b * p.out_bs + pix;
         optr[j] = nj < N ? o : nullptr;
+        xoff[j] = (long long)b * ((p.mul_pre ? p.mul_bs : p.act_bs) - p.out_bs);
     }
+    float am = 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float bias_v[16];          // this lane's 16 rows of the row tile: loaded together, branch-free
@@ -344,13 +386,45 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
         for (int j = 0; j < TN; ++j) {
             float* o = const_cast<float*>(optr[j]);
             if (o == nullptr) continue;
+            if (!fused) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                    if (m < p.M) o[(long long)m * plane] = split ? acc[i][j][r] : fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+                }
+            } else if (p.mul_pre != nullptr) {
+                // (scheduling fences: without them the compiler hoists every tile's loads to the top and the tall tiles spill)
+                const float* pre = p.mul_pre + ((o - p.out) + xoff[j]);
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float z[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int m = m0 + (wm * TM + i) * 32 + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lrow;
+                        z[r] = m < p.M ? pre[(long long)m * plane] : 0.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int m = m0 + (wm * TM + i) * 32 + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lrow;
+                        const float v = roottanh_grad_f(z[r], fmaf(acc[i][j][r0 + r], col_scale[j], bias_v[r0 + r]));
+                        if (m < p.M) { o[(long long)m * plane] = v; am = fmaxf(am, fabsf(v)); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                float* ao = p.act_out + ((o - p.out) + xoff[j]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                    const float v = fmaf(acc[i][j][r], col_scale[j], bias_v[r]);
+                    const float a = roottanh_f(v);
+                    if (m < p.M) { o[(long long)m * plane] = v; ao[(long long)m * plane] = a; am = fmaxf(am, fabsf(a)); }
+                    if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
+    if (fused && p.out_absmax != nullptr) absmax_publish_wave(am, p.out_absmax);
 }
 
 // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (private 4 MiB L2s), so

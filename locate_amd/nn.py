@@ -160,15 +160,34 @@ class SpectralNorm(_Bound):
                 pre = ops.sn_power_iteration(m.weight_bar, m.weight_u, m.weight_v)
         return tuple(pre) + (None,) * (3 - len(pre))
 
-    def forward(self, x, out=None):
-        """out (Conv2d / ConvTranspose2d only): a channel slice of a concatenation buffer to write the result into."""
+    def forward(self, x, out=None, in_link=None):
+        """out (Conv2d / ConvTranspose2d only): a channel slice of a concatenation buffer to write the result into.
+        in_link: x is the linked activation of the stage's previous conv (forward_act_linked)."""
         m = self.module
         x4, w4, spec, restore = self._plan(x)
         ops.carry_amax(x, x4)          # a reshaped view has its source's largest magnitude
         sigma, wv, guard = self.take_pre()
         y = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard,
-                        out if restore is _identity else None)
+                        out if restore is _identity else None, None, in_link)
         return restore(y)
+
+    def forward_act_linked(self, x, in_link=None):
+        """(RootTanh(layer(x)), link) from ONE launch, for the single consumer that takes `link` as its in_link - the next conv of
+        the stage (libs/conv.py:19-20, libs/attention.py:44-46): neither direction launches the activation (ops.ActLink).
+        None where the layer has no dense contraction (the SEPARABLE switch's grouped convs) or runs on the CPU."""
+        m = self.module
+        x4, w4, spec, restore = self._plan(x)
+        if spec.mode != "dense" or not x4.is_cuda or not ops.ACT_LINKS[0]:
+            return None
+        geom, out_shape = spec.geometry(tuple(x4.shape), tuple(w4.shape))
+        if out_shape[0] * out_shape[1] * out_shape[2] * out_shape[3] > ops.ACT_LINK_MAX_NUMEL[0]:
+            return None
+        ops.carry_amax(x, x4)
+        sigma, wv, guard = self.take_pre()
+        link = ops.ActLink()
+        _, second = ops.sn_conv(x4, w4, m.weight_u, m.weight_v, getattr(m, "bias", None), spec, (sigma, wv), self.runtime, guard,
+                                None, {"link": link}, in_link)
+        return restore(second), link
 
     def forward_activated(self, x, latent=None):
         """(layer(x), second) with second = RootTanh(layer(x)) - or, with `latent`, cat([latent, RootTanh(layer(x))], 1), the next
@@ -352,15 +371,20 @@ class _GateSequence(nn.Sequential):
     def forward(self, x):
         parts = list(self)
         i = 0
+        link = None          # x is the linked activation of the previous conv
         while i < len(parts):
             part = parts[i]
             if isinstance(part, SpectralNorm) and i + 1 < len(parts) and isinstance(parts[i + 1], RootTanhModule) and x.is_cuda:
-                fused = part.forward_activated(x)
+                fused = part.forward_act_linked(x, in_link=link)
+                if fused is None:
+                    fused = part.forward_activated(x)
+                    fused = None if fused is None else (fused[1], None)
                 if fused is not None:
-                    x = fused[1]
+                    x, link = fused
                     i += 2
                     continue
-            x = part(x)
+            x = part(x, in_link=link) if (link is not None and isinstance(part, SpectralNorm)) else part(x)
+            link = None
             i += 1
         return x
 
@@ -379,8 +403,12 @@ class SelfAttention(nn.Module):
         shape = function_input.shape
         rows = function_input.reshape(shape[0], shape[1], -1)          # [B, C, N]
         ops.carry_amax(function_input, rows)
-        for part in (self.conv_0, self.nlin_0, self.conv_1):
-            rows = part(rows)
+        fused = self.conv_0.forward_act_linked(rows) if rows.is_cuda else None
+        if fused is not None:
+            rows = self.conv_1(fused[0], in_link=fused[1])
+        else:
+            for part in (self.conv_0, self.nlin_0, self.conv_1):
+                rows = part(rows)
         return ops.softmax_lastdim(rows).view(shape)
 
 
@@ -398,6 +426,9 @@ class ActivatedBaseConv(nn.Module):
 
     def forward(self, function_input, pre_activated=False):
         h = function_input if pre_activated else ops.root_tanh(function_input)
+        fused = self.conv_0.forward_act_linked(h) if h.is_cuda else None
+        if fused is not None:          # conv_0's launch writes the activation, conv_1's input gradient multiplies by its derivative
+            return self.conv_1(fused[0], in_link=fused[1])
         return self.conv_1(ops.root_tanh(self.conv_0(h)))
 
 

@@ -16,9 +16,30 @@ _IntArr12 = ctypes.c_int * 12
 
 
 class _ActEpilogue(ctypes.Structure):
-    """LocateActEpilogue of include/locate_hip.h: the activated second output of locate_conv_fwd on 1x1 maps."""
+    """LocateActEpilogue of include/locate_hip.h: the activated second output of locate_conv_fwd / the multiplication by the
+    activation's derivative in locate_conv_dgrad."""
     _fields_ = [("act_out", ctypes.c_void_p), ("act_bs", ctypes.c_int64), ("lat", ctypes.c_void_p), ("lat_bs", ctypes.c_int64),
-                ("lat_z", ctypes.c_int32), ("pad", ctypes.c_int32)]
+                ("lat_z", ctypes.c_int32), ("pad", ctypes.c_int32), ("mul_pre", ctypes.c_void_p), ("mul_bs", ctypes.c_int64),
+                ("out_absmax", ctypes.c_void_p)]
+
+
+ACT_LINKS = [os.environ.get("LOCATE_ACT_LINKS", "1") != "0"]      # the fused activations of a stage (ActLink); off: launches of their own
+# ... up to this many activated elements: RootTanh is ~30 vector instructions per element, which a contraction's epilogue runs at
+# the contraction's occupancy (two or three blocks per CU) - on the large maps that costs what the separate launch and its
+# extra pass over the tensor cost (profiles/notes_r04_experiments.md section 6); on the small ones the launch is the cost
+ACT_LINK_MAX_NUMEL = [int(os.environ.get("LOCATE_ACT_LINK_MAX", str(1 << 40)))]
+
+
+class ActLink:
+    """Ties a conv whose launch also wrote a = RootTanh(y) (SNConvFn, act = {"link": ...}) to the ONE consumer of a, the next
+    conv of the stage (libs/conv.py:19-20, libs/attention.py:44-46): that conv's input-gradient launch multiplies by RootTanh'(y)
+    in its epilogue and says so here, and the producer's backward then takes the arriving gradient as the gradient of y -
+    the activation has no launch of its own in either direction."""
+    __slots__ = ("pre", "premultiplied")
+
+    def __init__(self):
+        self.pre = None
+        self.premultiplied = False
 
 
 def _stream():
@@ -1321,7 +1342,7 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
             FP8_CALLS[0] += 1
         adj = 0 if forward_of_r else 1
         # the window form (csrc/convwin.hip): the gathered operand staged in LDS once for all taps - where the geometry has it
-        win = epilogue is None and precision != 3 and _win_ok(geom, garr, adj | fmt, x)
+        win = precision != 3 and _win_ok(geom, garr, adj | fmt, x)
         if win:
             fmt |= 4
             prec |= 16
@@ -1337,7 +1358,8 @@ def _contract(forward_of_r, x, w, owner, spec, geom, garr, sigma, bias, y, preci
             if not win:
                 ws = _ws(L.locate_conv_dgrad_workspace_bytes(garr), x.device)
             check(L.locate_conv_dgrad(garr, _p(x), _bs(x), _p(_panel(owner, w, geom, garr, 1 | fmt)), _p(inv_sigma), sbg, sst, _p(bias), _p(y),
-                                      _bs(y), _p(ws), _p(_counters(owner, 1)), prec, _p(am), st), "locate_conv_dgrad")
+                                      _bs(y), _p(ws), _p(_counters(owner, 1)), prec, _p(am),
+                                      ctypes.addressof(epilogue) if epilogue is not None else None, st), "locate_conv_dgrad")
         return y
     if bias is not None:
         raise NotImplementedError("grouped convolutions carry no bias in the reference (libs/conv.py:15, libs/attention.py:18)")
@@ -1369,11 +1391,23 @@ def _conv_apply(x, w, owner, spec, geom, garr, sigma, bias, out_shape, precision
     return _contract(spec.kind == "conv", x, w, owner, spec, geom, garr, sigma, bias, y, precision, amax, epilogue)
 
 
-def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0, amax=None):
-    """Gradient w.r.t. the layer input."""
+def _conv_input_grad(gy, x_like, w, owner, spec, geom, garr, sigma, precision=0, amax=None, link=None):
+    """Gradient w.r.t. the layer input - with `link` (the input was RootTanh(link.pre), ActLink) w.r.t. link.pre: the launch's
+    epilogue multiplies by RootTanh'(link.pre), bit for bit what locate_roottanh_bwd makes of the plain input gradient."""
     if spec.mode == "groupdot":
         gy = gy.contiguous()
-    return _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, torch.empty_like(x_like), precision, amax)
+    gx = torch.empty_like(x_like)
+    epi = None
+    if link is not None:
+        pre = link.pre
+        slot = AMAX.slot(gx.device) if (gx.dim() >= 3 and gx.numel() >= AMAX_MIN_NUMEL[0]) else None
+        epi = _ActEpilogue(None, 0, None, 0, 0, 0, pre.data_ptr(), _bs(pre), _p(slot))
+    _contract(spec.kind != "conv", gy, w, owner, spec, geom, garr, sigma, None, gx, precision, amax, epi)
+    if link is not None:
+        link.premultiplied = True
+        if slot is not None:
+            _tag(gx, slot)
+    return gx
 
 
 def _raw_weight_grad(spec, geom, garr, xin, gout, gw, w_ref, inv_sigma, sbg, sst, partial, precision=0, amax_in=None, amax_out=None,
@@ -1508,7 +1542,7 @@ class SNConvFn(torch.autograd.Function):
     left by the latest forward, exactly like the reference's autograd does."""
 
     @staticmethod
-    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None, out_holder=None, act=None):
+    def forward(ctx, x, w_bar, u, v, bias, sigma, wv, spec, rt=None, guard=None, out_holder=None, act=None, in_link=None):
         # out_holder: [view] - the output is written into this channel slice of a concatenation buffer (hidden in a list so
         # that autograd does not see an input being returned)
         ctx.guard = guard              # (SpectralNormBatch, its ring sets): sigma / wv are views of them, still intact at backward?
@@ -1522,18 +1556,35 @@ class SNConvFn(torch.autograd.Function):
         ctx.amax_x = _amax_of(x)
         # act = {"latent": [B, z] or None}: second output RootTanh(y) from the same launch (1x1 maps) - alone as [B, M, 1, 1], or
         # as the next style link's input [B, z + M] = cat([latent, RootTanh(y)]) (libs/block.py:119-125)
-        epi = second = None
+        # act = {"link": ActLink}: the same on ANY map - second output RootTanh(y) [B, M, OH, OW] for the stage's next conv, whose
+        # input-gradient launch then multiplies by RootTanh'(y) itself (ActLink); its largest magnitude rides along
+        # in_link: this conv IS such a consumer (x = RootTanh(in_link.pre))
+        epi = second = second_amax = None
         ctx.act_z = None
+        ctx.act_link = act.get("link") if act is not None else None
+        ctx.in_link = in_link if (in_link is not None and spec.mode == "dense") else None
         if act is not None:
             Bn, Mn = out_shape[0], out_shape[1]
             lat = act.get("latent")
             z = 0 if lat is None else lat.shape[1]
             second = torch.empty((Bn, z + Mn) if lat is not None else out_shape, dtype=torch.float32, device=x.device)
-            epi = _ActEpilogue(second.data_ptr() + 4 * z, z + Mn, _p(lat), 0 if lat is None else lat.stride(0), z, 0)
+            if ctx.act_link is not None:
+                if lat is not None or out_holder:
+                    raise ValueError("an activation link excludes a latent prefix and an output slice")
+                plane_elems = second.numel() // Bn
+                if second.dim() >= 3 and second.numel() >= AMAX_MIN_NUMEL[0]:
+                    second_amax = AMAX.slot(x.device)
+                epi = _ActEpilogue(second.data_ptr(), plane_elems, None, 0, 0, 0, None, 0, _p(second_amax))
+            else:
+                epi = _ActEpilogue(second.data_ptr() + 4 * z, z + Mn, _p(lat), 0 if lat is None else lat.stride(0), z, 0, None, 0, None)
             if lat is not None and (lat.stride(1) != 1 or lat.shape[0] != Bn):
                 raise ValueError("style latent must be [B, z] with contiguous rows")
             ctx.act_z = z
         y = _conv_apply(x, w, owner, spec, geom, garr, sigma, b, out_shape, rt.precision, ctx.amax_x, out_holder[0] if out_holder else None, epi)
+        if ctx.act_link is not None:
+            ctx.act_link.pre = y
+            if second_amax is not None:
+                _tag(second, second_amax)
         groups = sigma.shape[0] if sigma.dim() == 2 else 1
         ctx.groups = groups
         if groups > 1:
@@ -1565,10 +1616,17 @@ class SNConvFn(torch.autograd.Function):
         else:
             x, w, sigma, wv = ctx.saved_tensors
             y = bsaved = None
-        if ctx.act_z is not None and g_second is not None:
+        if ctx.act_link is not None and g_second is not None and ctx.act_link.premultiplied:
+            # the consumer's input-gradient launch has already multiplied by RootTanh'(y): g_second IS the gradient of y
+            ctx.act_link.premultiplied = False
+            if gy is not None:
+                raise RuntimeError("a linked pre-activation has one consumer, its activation")
+            gy = g_second.reshape(pre.shape) if g_second.shape != pre.shape else g_second
+        elif ctx.act_z is not None and g_second is not None:
             # gradient through the activated second output joins the pre-activation's own (a norm's style scale, or none):
             # gy <- gy + RootTanh'(y) * g_second[:, z:]   - one launch (locate_act_rows_bwd), bit for bit autograd's sum
-            Bn, Mn = pre.shape[0], pre.shape[1]
+            Bn = pre.shape[0]
+            Mn = pre.numel() // Bn          # (rows of a 1x1 map; a linked activation on a larger map whose consumer did not multiply)
             g2 = _chk(g_second, "activated output gradient")
             if g2.dim() != 2:
                 g2 = g2.reshape(Bn, -1)
@@ -1580,7 +1638,7 @@ class SNConvFn(torch.autograd.Function):
                   "locate_act_rows_bwd")
             gy = total
         if gy is None:
-            return (None,) * 12
+            return (None,) * 13
         spec, garr = ctx.spec, _geom(ctx.geom)
         if ctx.guard is not None:
             ctx.guard[0].check(ctx.guard[1])
@@ -1589,7 +1647,7 @@ class SNConvFn(torch.autograd.Function):
         need_x, need_w, need_u, need_v, need_b = ctx.needs_input_grad[:5]
         gx = gw = gu = gb = None
         if need_x:
-            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma, ctx.rt.precision, amax_gy)
+            gx = _conv_input_grad(gy, x, w, ctx.owner, spec, ctx.geom, garr, sigma, ctx.rt.precision, amax_gy, ctx.in_link)
         if need_w or need_u or need_v:
             rt = ctx.rt
             side = rt.weight_grad_stream
@@ -1622,14 +1680,14 @@ class SNConvFn(torch.autograd.Function):
             else:
                 gb = _bias_grad(gy)
         # gv is assigned to v.grad by Runtime._finalize_dv at the end of this backward pass
-        return gx, gw, gu, None, gb, None, None, None, None, None, None, None
+        return gx, gw, gu, None, gb, None, None, None, None, None, None, None, None
 
 
-def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None, out=None, act=None):
+def sn_conv(x, w_bar, u, v, bias, spec, sigma_wv=None, runtime=None, guard=None, out=None, act=None, in_link=None):
     """Spectral-normalised contraction.  Runs the power iteration unless (sigma, wv) of an already executed
     batched update is supplied (guard: see SNConvFn.forward).  out: view to write the result into (see _conv_apply).
     act: see SNConvFn.forward - returns (y, second output) then."""
     if sigma_wv is None:
         sigma_wv = sn_power_iteration(w_bar, u, v)
     sigma, wv = sigma_wv
-    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard, None if out is None else [out], act)
+    return SNConvFn.apply(x, w_bar, u, v, bias, sigma, wv, spec, runtime, guard, None if out is None else [out], act, in_link)

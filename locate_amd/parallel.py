@@ -126,8 +126,11 @@ class GradAllReducer:
         # the backward kernels of this package write parameter gradients there (ops._grad_home), so a bucket whose gradients all
         # sit at home is all-reduced where it lies - no packing before, no scattering after the collective
         self.sent_in_place = self.sent_packed = 0          # buckets sent from their resident buffer / through a packed copy (bench.py)
+        self.collectives = 0                               # collectives issued for them (a segment group's buckets can share one)
         self._home = [None] * len(self.buckets)
         self._home_off = {}
+        self._home_span = {}       # bucket -> (segment group, start, end) inside the group's allocation
+        self._ghome = {}           # segment group -> its buckets' resident buffers, back to back
         self._handles = []
         self._ready = None
         self._launched = None
@@ -138,6 +141,15 @@ class GradAllReducer:
         # optional timing (bench.py): HIP events around every bucket's pack -> all-reduce -> unpack on the side stream, and
         # around the compute stream's join in finish() - the part of the exchange that is NOT hidden behind backward work
         self.timing = False
+        # direct: a bucket that is reduced where it lies and needs no scaling afterwards (resident bucket / solo gradient, RCCL's own
+        # averaging) is handed to the process group straight from the compute stream - torch runs collectives on the group's own
+        # stream anyway, behind an event of the caller's - and the compute stream waits for it in finish().  Through the reducer's
+        # side stream the same bucket crossed four stream boundaries (compute -> side -> group -> side -> compute: ~75 us of idle
+        # chip per pass in the one-rank RCCL rehearsal, profiles/notes_r04_experiments.md section 4) instead of two.  Every
+        # collective still runs on the group's one stream, in issue order.  Buckets that are packed or scaled keep the side stream.
+        import os
+        self.direct = os.environ.get("LOCATE_DP_DIRECT", "1") != "0"
+        self._side_used = False
         self._t_comm = []          # (start, end) event pairs on the side stream
         self._t_wait = []          # (start, end) event pairs on the compute stream
 
@@ -194,6 +206,7 @@ class GradAllReducer:
         in_place = own is not None
         self.sent_in_place += int(in_place)
         self.sent_packed += int(not in_place)
+        direct = self.direct and in_place and dev.type == "cuda" and (self._avg or self.world == 1)
         if in_place:
             flat = own                          # the gradient itself / the resident bucket: reduced where it lies
         else:
@@ -201,6 +214,15 @@ class GradAllReducer:
             if flat is None or flat.numel() != total or flat.device != dev:
                 flat = torch.empty(total, dtype=grads[0].dtype, device=dev)
                 self._flat[b] = flat
+        if direct:
+            ev = None
+            if self.timing:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(dev))
+            work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
+            self.collectives += 1
+            self._handles.append((b, members, work, flat, ev, True))
+            return
         if dev.type == "cuda":
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -213,11 +235,13 @@ class GradAllReducer:
                 if not in_place:
                     self._pack(b, flat, grads)
                 work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
+            self._side_used = True
         else:
             if not in_place:
                 self._pack(b, flat, grads)
             work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
-        self._handles.append((b, members, work, flat if in_place else None))
+        self.collectives += 1
+        self._handles.append((b, members, work, flat if in_place else None, None, False))
 
     def _in_place(self, b, grads, members=None):
         """The tensor to all-reduce in place, or None: a solo gradient itself; or the bucket's resident buffer when every gradient
@@ -238,6 +262,9 @@ class GradAllReducer:
         on their device - TrainStep does, before the first backward pass)."""
         if not self.enabled:
             return
+        # the buckets of one segment group lie back to back in ONE allocation: under hipGraph replay, where every gradient of a
+        # segment is complete when launch_group() / finish() runs, the group goes out as a single collective (_launch_merged)
+        todo = {}
         for b, idxs in enumerate(self.buckets):
             if self._home[b] is not None or not idxs or self.bucket_solo[b]:
                 continue
@@ -245,13 +272,23 @@ class GradAllReducer:
             dev = ps[0].device
             if any(q.device != dev or q.dtype != torch.float32 for q in ps):
                 continue
-            home = torch.zeros(sum(q.numel() for q in ps), dtype=torch.float32, device=dev)
-            off = 0
-            for i, q in zip(idxs, ps):
-                self._home_off[i] = off
-                q.__dict__["_locate_grad_buf"] = home[off:off + q.numel()].view(q.shape)
-                off += q.numel()
-            self._home[b] = home
+            todo.setdefault((self.bucket_group[b], dev), []).append(b)
+        for (gi, dev), bs in todo.items():
+            sizes = [sum(self.params[i].numel() for i in self.buckets[b]) for b in bs]
+            ghome = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            start = 0
+            for b, n in zip(bs, sizes):
+                home = ghome[start:start + n]
+                off = 0
+                for i in self.buckets[b]:
+                    q = self.params[i]
+                    self._home_off[i] = off
+                    q.__dict__["_locate_grad_buf"] = home[off:off + q.numel()].view(q.shape)
+                    off += q.numel()
+                self._home[b] = home
+                self._home_span[b] = (gi, start, start + n)
+                start += n
+            self._ghome[gi] = ghome
 
     def _check_agreement(self, b, members):
         """Which parameters have a gradient is decided per rank (`grad is not None`); ranks that disagreed would exchange
@@ -294,12 +331,40 @@ class GradAllReducer:
         if not self.enabled:
             return
         first = len(self._handles)
-        for b, g in enumerate(self.bucket_group):
-            if g == gi and not self._launched[b]:
-                self._launch(b)
+        self._launch_buckets([b for b, g in enumerate(self.bucket_group) if g == gi and not self._launched[b]])
         # their results go back into the .grad tensors as soon as each collective is done - on the side stream, beside the next
         # segment's backward - instead of at finish(), where the compute stream would wait for the copies as well
         self._unpack_handles(first)
+
+    def _launch_buckets(self, bs):
+        """Send the given buckets of ONE segment group: as one collective over the group's allocation where every one of them is
+        reduced in place from its resident buffer (replayed steps, direct hand-over), else one by one."""
+        if len(bs) > 1 and self.direct and self._replaying and all(b in self._home_span for b in bs):
+            own = []
+            for b in bs:
+                members = [i for i in self.buckets[b] if self.params[i].grad is not None]
+                grads = [self.params[i].grad for i in members]
+                own.append(self._in_place(b, grads, members) if members else None)
+            if all(o is not None and o is self._home[b] and o.is_cuda for o, b in zip(own, bs)) and (self._avg or self.world == 1):
+                gi = self._home_span[bs[0]][0]
+                lo = min(self._home_span[b][1] for b in bs)
+                hi = max(self._home_span[b][2] for b in bs)
+                flat = self._ghome[gi][lo:hi]
+                for b in bs:
+                    members = [i for i in self.buckets[b] if self.params[i].grad is not None]
+                    self._launched[b] = True
+                    self._check_agreement(b, members)
+                    self.sent_in_place += 1
+                ev = None
+                if self.timing:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(torch.cuda.current_stream(flat.device))
+                work = dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True)
+                self.collectives += 1
+                self._handles.append((bs[0], [], work, flat, ev, True))
+                return
+        for b in bs:
+            self._launch(b)
 
     @staticmethod
     def _views(flat, grads):
@@ -350,11 +415,11 @@ class GradAllReducer:
         if not self.enabled:
             return
         self._active = False
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
-        self._unpack_handles(0)
-        if self._side is not None:
+        for gi in range(self.n_groups):
+            self._launch_buckets([b for b, g in enumerate(self.bucket_group) if g == gi and not self._launched[b]])
+        self._unpack_handles(0, final=True)
+        if self._side is not None and self._side_used:
+            self._side_used = False
             cur = torch.cuda.current_stream(self._side.device)
             if self.timing:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -366,13 +431,32 @@ class GradAllReducer:
                 cur.wait_stream(self._side)
         self._handles = []
 
-    def _unpack_handles(self, first):
-        """Wait (stream-ordered on the GPU) for the collectives launched since handle `first` and scatter their results."""
+    def _unpack_handles(self, first, final=False):
+        """Wait (stream-ordered on the GPU) for the collectives launched since handle `first` and scatter their results.
+        Direct buckets (see __init__) are joined by the compute stream itself, and only at finish() (final)."""
         inv = None if self._avg else 1.0 / self.world
         for k in range(first, len(self._handles)):
             if self._handles[k] is None:
                 continue
-            b, members, work, own = self._handles[k]
+            b, members, work, own, ev, direct = self._handles[k]
+            if direct:
+                if not final:
+                    continue
+                self._handles[k] = None
+                cur = torch.cuda.current_stream(own.device)
+                a = None
+                if self.timing:
+                    a = torch.cuda.Event(enable_timing=True)
+                    a.record(cur)
+                work.wait()                      # the compute stream waits for the group's stream
+                if inv is not None:
+                    own.mul_(inv)
+                if a is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(cur)
+                    self._t_wait.append((a, e))
+                    self._t_comm.append([ev, e])          # (launch ... join on the compute stream: an upper bound of the exchange)
+                continue
             self._handles[k] = None
             flat = own if own is not None else self._flat[b]
             dev = flat.device

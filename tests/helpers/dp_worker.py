@@ -21,7 +21,14 @@ def main():
     overlap_wgrad = mode.endswith("+wg")
     mode = mode.split("+")[0]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # LOCATE_TEST_BACKEND=nccl (world 1 only): the RCCL path itself - reducers forced on at world size 1, so that the direct
+    # hand-over to the process group's stream and the one-collective-per-segment form of the replayed step are exercised
+    backend = os.environ.get("LOCATE_TEST_BACKEND", "gloo")
+    force = backend == "nccl"
+    if force:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from locate_amd import Discriminator, Generator, Nadam, NetConfig, TrainStep
     from locate_amd.graph import GraphedTrainStep
     from locate_amd.parallel import GradAllReducer, broadcast_module_state
@@ -41,8 +48,8 @@ def main():
     G.batched_spectral_norm = D.batched_spectral_norm = True
     d_cut = 2
     late_v = [p for n, p in D.named_parameters() if n.endswith("weight_v")]
-    red_g = GradAllReducer(G.parameters(), bucket_bytes=64 << 10)          # small buckets: several per network
-    red_d = GradAllReducer(D.parameters(), bucket_bytes=64 << 10, late=late_v, groups=D.segment_parameters(d_cut))
+    red_g = GradAllReducer(G.parameters(), bucket_bytes=64 << 10, force=force)          # small buckets: several per network
+    red_d = GradAllReducer(D.parameters(), bucket_bytes=64 << 10, late=late_v, groups=D.segment_parameters(d_cut), force=force)
     step = TrainStep(G, D, Nadam(G.parameters(), lr=cfg.glr, betas=(cfg.beta1, cfg.beta2)),
                      Nadam(D.parameters(), lr=cfg.dlr, betas=(cfg.beta1, cfg.beta2)), reducer_g=red_g, reducer_d=red_d, d_cut=d_cut,
                      overlap_wgrad=overlap_wgrad)
@@ -75,6 +82,9 @@ def main():
             for _ in range(2 + replays):
                 step(*shard)
     torch.cuda.synchronize()
+    rec["stats"] = {"enabled": bool(red_d.enabled), "collectives": (red_d.collectives, red_g.collectives),
+                    "in_place": (red_d.sent_in_place, red_g.sent_in_place), "packed": (red_d.sent_packed, red_g.sent_packed),
+                    "buckets": (len(red_d.buckets), len(red_g.buckets))}
     rec["G"] = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
     rec["D"] = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
     torch.save(rec, out_path)

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 T = torch.as_tensor
 
 
-def _run_ranks(tmp_path, mode, world=2):
+def _run_ranks(tmp_path, mode, world=2, backend=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = str(s.getsockname()[1])
@@ -31,6 +31,8 @@ def _run_ranks(tmp_path, mode, world=2):
     worker = os.path.join(ROOT, "tests", "helpers", "dp_worker.py")
     outs = [str(tmp_path / ("%s_rank%d.pt" % (mode, r))) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend:
+        env["LOCATE_TEST_BACKEND"] = backend
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, golden, outs[r], mode], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
@@ -108,3 +110,22 @@ def test_dp_graph_replay_with_segmented_backward_equals_eager(tmp_path, suffix):
         for k, v in graph[0][net].items():
             assert torch.equal(v, graph[1][net][k]), ("replicas diverged under graph replay", net, k)
             assert_close(v, eager[0][net][k], 1e-5, "graph vs eager " + net + " " + k)
+
+
+def test_one_rank_rccl_replay_sends_one_collective_per_segment_and_changes_nothing(tmp_path):
+    """The RCCL path itself, as far as one GPU can run it (world size 1, reducers forced on): the replayed step hands every
+    backward segment's resident buckets to the process group as ONE collective, straight from the compute stream (parallel.py:
+    direct / _launch_buckets).  At world size 1 the average is the identity, so the run must end where a run without any
+    reducer ends - a bucket that missed its exchange, was scaled twice or raced with the optimizer would show."""
+    plain = _run_ranks(tmp_path, "eager4", world=1)[0]
+    assert not plain["stats"]["enabled"]
+    rccl = _run_ranks(tmp_path, "graph", world=1, backend="nccl")[0]
+    st = rccl["stats"]
+    assert st["enabled"]
+    sent = sum(st["in_place"]) + sum(st["packed"])
+    assert st["buckets"][0] >= 3 and st["buckets"][1] >= 2
+    assert sum(st["collectives"]) < sent, ("no segment was merged into one collective", st)
+    assert sum(st["in_place"]) > sum(st["packed"]), st
+    for net in ("G", "D"):
+        for k, v in rccl[net].items():
+            assert_close(v, plain[net][k], 1e-5, "one-rank RCCL replay vs no reducer: " + net + " " + k)

@@ -486,6 +486,67 @@ def test_conv_window_form_stacked_calls_and_repack(monkeypatch):
     ops._WIN_CACHE.clear()
 
 
+ACT_LINK_CASES = [
+    # (conv class name, cin, mid, cout, kernel, stride, pad, batch, H)  - conv_0 (k x k) -> RootTanh -> conv_1 (1 x 1)
+    ("ConvTranspose2d", 192, 192, 96, 4, 2, 1, 64, 16),      # tall tiles, four sub-pixel phases; conv_1 single-tap window form
+    ("ConvTranspose2d", 64, 64, 64, 4, 2, 1, 8, 2),          # 2x2 -> 4x4: the staged small-plane epilogue
+    ("Conv2d", 48, 48, 48, 3, 1, 1, 16, 32),                 # 3x3; conv_1 through the narrow pointwise stream (M, K <= 64, >= 131072 pixels)
+    ("Conv2d", 64, 64, 64, 5, 2, 2, 24, 16),                 # the discriminator's 5x5 stride-2 conv, batch 24
+    ("Conv2d", 256, 256, 256, 5, 2, 2, 6, 4),                # deep layer: split-K with the separate reduction launch
+    ("Conv2d", 40, 72, 24, 3, 1, 1, 3, 7),                   # ragged everything
+    ("Conv2d", 128, 128, 64, 1, 1, 0, 16, 1),                # 1x1 maps: the rows kernel on both sides
+]
+
+
+@pytest.mark.parametrize("case", ACT_LINK_CASES, ids=lambda c: "%s-%d-%d-%d-k%d-s%d-b%d-%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[7], c[8]))
+@pytest.mark.parametrize("form", ["f16x2", "bf16x3"])
+def test_linked_activation_equals_separate_launches(case, form, monkeypatch):
+    """conv_0 -> RootTanh -> conv_1 of a stage (libs/conv.py:19-20) with the activation written by conv_0's epilogue and its
+    derivative applied by conv_1's input-gradient epilogue (ops.ActLink) against the same stage with the two RootTanh launches of
+    their own: output, input gradient and every parameter gradient bit for bit (same products, same order, same roundings)."""
+    from locate_amd import ops
+    from locate_amd.nn import ActivatedBaseConv
+    import copy
+    cls, cin, mid, cout, k, s, pad, B, H = case
+    monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0 if form == "f16x2" else 1e30)
+    monkeypatch.setattr(ops, "AMAX_MIN_NUMEL", [1])
+    monkeypatch.setattr(ops, "ACT_LINKS", [True])
+    torch.manual_seed(11)
+
+    class Cfg:
+        feature_multiplier = 1
+        separable = False
+    stage = ActivatedBaseConv(cin, cout, getattr(torch.nn, cls), kernel=k, stride=s, pad=pad, cfg=Cfg)
+    if mid != cin:          # (the reference ties the bottleneck width to the input's; widen it for the ragged case)
+        from locate_amd import SpectralNorm
+        stage.conv_0 = SpectralNorm(getattr(torch.nn, cls)(cin, mid, k, s, pad, bias=False))
+        stage.conv_1 = SpectralNorm(getattr(torch.nn, cls)(mid, cout, 1, 1, 0, bias=False))
+    x0 = torch.randn(B, cin, H, H) * 1.5
+    results = []
+    for linked in (True, False):
+        ops.ACT_LINKS[0] = linked
+        st = copy.deepcopy(stage).to(dev())
+        for prm in st.parameters():
+            prm.requires_grad_(True)
+        x = ops.tag_amax(x0.to(dev())).requires_grad_(True)
+        before = (ops.F16_CALLS["fwd"], ops.F16_CALLS["dgrad"])
+        y = st(x, pre_activated=True)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev())
+        ops.reset_backward_state()
+        y.backward(ops.tag_amax(gy))
+        torch.cuda.synchronize()
+        if form == "f16x2" and H > 1:
+            assert ops.F16_CALLS["fwd"] > before[0], "the fp16-piece form was not taken"
+        results.append((y.detach().clone(), x.grad.clone(), [(n, prm.grad.clone()) for n, prm in st.named_parameters() if prm.grad is not None]))
+    (ya, gxa, pa), (yb, gxb, pb) = results
+    assert torch.isfinite(ya).all() and float(ya.abs().max()) > 0
+    assert torch.equal(ya, yb), "stage output"
+    assert torch.equal(gxa, gxb), "input gradient"
+    assert [n for n, _ in pa] == [n for n, _ in pb] and len(pa) >= 4
+    for (n, a), (_, b) in zip(pa, pb):
+        assert torch.equal(a, b), n
+
+
 def test_stale_largest_magnitude_tag_is_ignored(monkeypatch):
     """A tensor's largest-magnitude words are only valid for the data they were taken from: when autograd sums a second consumer's
     gradient INTO a tagged gradient (in place), the contraction that consumes the sum must not scale its fp16 pieces by the old
@@ -1320,7 +1381,7 @@ def test_direct_repack_equals_two_pass_repack(kind, cin, cout, k, s, p, B, H, fm
         inp2, out2, pan2, ax2 = (gy, torch.empty_like(x), res[1][which], amax[nw:]) if kind == "conv" else \
                                 (x, torch.empty(out_shape, device=dev()), res[1][which], amax[0:])
         check(L.locate_conv_dgrad(garr, inp2.data_ptr(), inp2.stride(0), pan2.data_ptr(), one.data_ptr(), 0, 0, None, out2.data_ptr(),
-                                  out2.stride(0), ws.data_ptr(), None, 2 if fmt else 0, ax2.data_ptr() if fmt else None, S()), "locate_conv_dgrad")
+                                  out2.stride(0), ws.data_ptr(), None, 2 if fmt else 0, ax2.data_ptr() if fmt else None, None, S()), "locate_conv_dgrad")
         outs.append((out, out2))
     torch.cuda.synchronize()
     assert any(seen_direct)

@@ -123,7 +123,7 @@ def bench_shape(kind, cin, cout, kh, kw, s, ph, pw, B, H, W, reps=20, prec=0, us
 
     def r_dgrad(inp, out):    # R data adjoint
         check(L.locate_conv_dgrad(garr, inp.data_ptr(), inp.stride(0), pan1.data_ptr(), one.data_ptr(), 0, 0, None, out.data_ptr(),
-                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec | (16 if win1 else 0), slot[inp.data_ptr()] if prec == 2 else None, S()))
+                                  out.stride(0), ws_d.data_ptr(), cnt_d.data_ptr() if use_cnt else None, prec | (16 if win1 else 0), slot[inp.data_ptr()] if prec == 2 else None, None, S()))
 
     if kind == "conv":
         fwd, dgr = (lambda: r_fwd(x, y)), (lambda: r_dgrad(gy, gx))
