@@ -27,7 +27,9 @@ ACT_LINKS = [os.environ.get("LOCATE_ACT_LINKS", "1") != "0"]      # the fused ac
 # ... up to this many activated elements: RootTanh is ~30 vector instructions per element, which a contraction's epilogue runs at
 # the contraction's occupancy (two or three blocks per CU) - on the large maps that costs what the separate launch and its
 # extra pass over the tensor cost (profiles/notes_r04_experiments.md section 6); on the small ones the launch is the cost
-ACT_LINK_MAX_NUMEL = [int(os.environ.get("LOCATE_ACT_LINK_MAX", str(1 << 40)))]
+# (same-box A/B at config 2, bench.py --step-only, two rounds each: off 9.56 / 9.55, up to 0.3 M elements 9.49 / 9.50, 1 M 9.51 /
+# 9.51, 4 M 9.48 / 9.51, 8 M 9.50 / 9.50, every stage 9.54 / 9.54)
+ACT_LINK_MAX_NUMEL = [int(os.environ.get("LOCATE_ACT_LINK_MAX", str(1 << 22)))]
 
 
 class ActLink:

@@ -511,6 +511,7 @@ def test_linked_activation_equals_separate_launches(case, form, monkeypatch):
     monkeypatch.setattr(ops, "F16_MIN_FLOPS", 0.0 if form == "f16x2" else 1e30)
     monkeypatch.setattr(ops, "AMAX_MIN_NUMEL", [1])
     monkeypatch.setattr(ops, "ACT_LINKS", [True])
+    monkeypatch.setattr(ops, "ACT_LINK_MAX_NUMEL", [1 << 40])
     torch.manual_seed(11)
 
     class Cfg:
