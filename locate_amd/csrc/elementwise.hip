@@ -378,6 +378,73 @@ __global__ void __launch_bounds__(256) gate_bwd_plane_kernel(const float* __rest
     if (da_absmax && !a_per_plane) absmax_publish(am, amax_scratch, da_absmax);
 }
 
+// The same for SMALL planes (hw a multiple of 4, at most 128 elements: the 2x2 ... 8x8 maps of the deep blocks, where B x C is
+// tens of thousands of planes): LP lanes per plane, 64 / LP planes per wave and pass - one 16-byte access per lane.  With a whole
+// wave per 4-element plane one lane worked, every plane paid two full wave reductions (the double one: 12 shuffles of 8 bytes) and
+// a wave walked ~50 planes one after the other: 25 - 70 us for tensors of a few hundred KB.  Per-plane sums: the same additions
+// in the same order as gate_bwd_plane_kernel<1> (whose idle lanes add exact zeros), hence the same bits.
+template <int LP>
+__global__ void __launch_bounds__(256) gate_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                             const float* __restrict__ gamma, const float* __restrict__ g,
+                                                             float* __restrict__ dx, float* __restrict__ da_full,
+                                                             float* __restrict__ da_plane, double* __restrict__ block_x2g,
+                                                             int64_t planes, int hw, int a_per_plane, int accumulate_dx,
+                                                             unsigned* __restrict__ da_absmax) {
+    __shared__ double wsum[4];
+    __shared__ float amax_scratch[16];
+    constexpr int PW = 64 / LP;
+    float am = 0.0f;
+    double wacc = 0.0;
+    const float gm = gamma[0];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int gid = lane / LP, li = lane % LP;
+    const int q4 = hw >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p0 = wave * PW; p0 < planes; p0 += nwaves * PW) {
+        const int64_t p = p0 + gid;
+        const bool live = p < planes;
+        float sxg = 0.0f, sx2g = 0.0f;
+        if (live && li < q4) {
+            const int64_t base = p * hw;
+            const float ap = a_per_plane ? a[p] : 0.0f;
+            const float4 xv = reinterpret_cast<const float4*>(x + base)[li], gv = reinterpret_cast<const float4*>(g + base)[li];
+            float4 av = make_float4(ap, ap, ap, ap);
+            if (!a_per_plane) av = reinterpret_cast<const float4*>(a + base)[li];
+            const float4 xg = make_float4(xv.x * gv.x, xv.y * gv.y, xv.z * gv.z, xv.w * gv.w);
+            float4 o = make_float4(fmaf(gm, av.x, 1.0f) * gv.x, fmaf(gm, av.y, 1.0f) * gv.y, fmaf(gm, av.z, 1.0f) * gv.z,
+                                   fmaf(gm, av.w, 1.0f) * gv.w);
+            if (accumulate_dx) {
+                const float4 old = reinterpret_cast<const float4*>(dx + base)[li];
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            reinterpret_cast<float4*>(dx + base)[li] = o;
+            if (!a_per_plane) {
+                const float4 dav = make_float4(xg.x * gm, xg.y * gm, xg.z * gm, xg.w * gm);
+                reinterpret_cast<float4*>(da_full + base)[li] = dav;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(dav.x), fabsf(dav.y))), fmaxf(fabsf(dav.z), fabsf(dav.w)));
+            }
+            sxg = (xg.x + xg.y) + (xg.z + xg.w);
+            sx2g = (xg.x * xv.x + xg.y * xv.y) + (xg.z * xv.z + xg.w * xv.w);
+        }
+        double s2 = (double)sx2g;
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) {
+            sxg += __shfl_xor(sxg, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if (live && li == 0) {
+            wacc += s2;
+            if (a_per_plane) da_plane[p] = gm * sxg;
+        }
+    }
+    wacc = wave_sum_d(wacc);          // the plane leaders' sums (other lanes hold 0), fixed order
+    if (lane == 0) wsum[wid] = wacc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_x2g[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (da_absmax && !a_per_plane) absmax_publish(am, amax_scratch, da_absmax);
+}
+
 // dgamma = sum over blocks of block_x2g (reference bug: x^2 g, merge.py:33-38)
 __global__ void __launch_bounds__(256) gate_bwd_final_kernel(const double* __restrict__ block_x2g, float* __restrict__ dgamma,
                                                              int nblocks) {
@@ -432,7 +499,19 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
     double* block_x2g = static_cast<double*>(workspace);
     const bool whole_block = hw >= 1024;
     const int64_t blocks = gate_bwd_blocks(planes, hw);
-    if (whole_block)
+    const bool vec = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
+                                        (a_per_plane ? 0 : (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(da)))) & 15) == 0;
+#define GATE_SMALL(LPV) gate_bwd_small_kernel<LPV><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da, \
+        a_per_plane ? da : nullptr, block_x2g, planes, hw, a_per_plane, accumulate_dx, static_cast<unsigned*>(da_absmax))
+    if (vec && hw <= 128) {
+        const int q4 = hw >> 2;
+        if (q4 <= 1) GATE_SMALL(1);
+        else if (q4 <= 2) GATE_SMALL(2);
+        else if (q4 <= 4) GATE_SMALL(4);
+        else if (q4 <= 8) GATE_SMALL(8);
+        else if (q4 <= 16) GATE_SMALL(16);
+        else GATE_SMALL(32);
+    } else if (whole_block)
         gate_bwd_plane_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(x, a, gamma, g, dx, a_per_plane ? nullptr : da,
                                                                             a_per_plane ? da : nullptr, block_x2g, planes, hw,
                                                                             a_per_plane, accumulate_dx, static_cast<unsigned*>(da_absmax));

@@ -271,6 +271,94 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_kernel(const float* __rest
     }
 }
 
+// Pass 1 for SMALL planes (hw a multiple of 4, at most 128 elements - see gate_bwd_small_kernel, elementwise.hip): LP lanes per
+// plane, 64 / LP planes per wave and pass.  S1 / S2: the same additions in the same order as the wave-per-plane kernel.
+template <bool ACT, int LP>
+__global__ void __launch_bounds__(256) norm_bwd_plane_small_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                   const float* __restrict__ stats, const float* __restrict__ scale,
+                                                                   int scale_per_sample, const float* __restrict__ bias, int C,
+                                                                   float* __restrict__ S1, float* __restrict__ S2, int64_t planes,
+                                                                   int64_t planes_g, int hw, double* __restrict__ block_partial,
+                                                                   float* __restrict__ dscale_sample) {
+    __shared__ double bp[4][NORM_MAX_GROUPS][2];
+    constexpr int PW = 64 / LP;
+    double acc_a[NORM_MAX_GROUPS], acc_b[NORM_MAX_GROUPS];
+#pragma unroll
+    for (int q = 0; q < NORM_MAX_GROUPS; ++q) acc_a[q] = acc_b[q] = 0.0;
+    const int lane = threadIdx.x & 63;
+    const int gid = lane / LP, li = lane % LP;
+    const int q4 = hw >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p0 = wave * PW; p0 < planes; p0 += nwaves * PW) {
+        const int64_t p = p0 + gid;
+        const bool live = p < planes;
+        const int64_t pp = live ? p : planes - 1;
+        const int grp = (int)(pp / planes_g);
+        const float mu = stats[2 * grp], sd = stats[2 * grp + 1], inv_sd = 1.0f / sd;
+        const int c = (int)(pp % C);
+        const float yv = (ACT || block_partial != nullptr) ? scale[scale_per_sample ? pp : c] : 0.0f;
+        const float y = ACT ? yv : 0.0f, b = ACT ? bias[c] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (live && li < q4) {
+            const float4 xv = reinterpret_cast<const float4*>(x + pp * hw)[li];
+            float4 gv = reinterpret_cast<const float4*>(g + pp * hw)[li];
+            gv.x = norm_go<ACT>(xv.x, gv.x, mu, inv_sd, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, inv_sd, y, b);
+            gv.z = norm_go<ACT>(xv.z, gv.z, mu, inv_sd, y, b); gv.w = norm_go<ACT>(xv.w, gv.w, mu, inv_sd, y, b);
+            s1 = (gv.x + gv.y) + (gv.z + gv.w);
+            s2 = ((xv.x - mu) * gv.x + (xv.y - mu) * gv.y) + ((xv.z - mu) * gv.z + (xv.w - mu) * gv.w);
+        }
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if (live && li == 0) {
+            S1[p] = s1;
+            S2[p] = s2;
+            if (block_partial) {
+#pragma unroll
+                for (int q = 0; q < NORM_MAX_GROUPS; ++q)
+                    if (q == grp) {
+                        acc_a[q] += (double)yv * (double)s1;
+                        acc_b[q] += (double)yv * (double)s2;
+                    }
+                if (dscale_sample) dscale_sample[p] = s2 / sd;
+            }
+        }
+    }
+    if (block_partial) {          // the plane leaders' sums over the wave (fixed order), then the four waves in wave order
+        const int wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < NORM_MAX_GROUPS; ++q) {
+            const double a = wave_sum_d(acc_a[q]), bsum = wave_sum_d(acc_b[q]);
+            if (lane == 0) { bp[wid][q][0] = a; bp[wid][q][1] = bsum; }
+        }
+        __syncthreads();
+        if (threadIdx.x < NORM_MAX_GROUPS * 2) {
+            const int q = threadIdx.x >> 1, e = threadIdx.x & 1;
+            block_partial[((int64_t)blockIdx.x * NORM_MAX_GROUPS + q) * 2 + e] = ((bp[0][q][e] + bp[1][q][e]) + bp[2][q][e]) + bp[3][q][e];
+        }
+    }
+}
+
+template <bool ACT>
+static bool launch_norm_plane_small(int blocks, hipStream_t st, const float* x, const float* g, const float* stats, const float* scale,
+                                    int scale_per_sample, const float* bias, int C, float* S1, float* S2, int64_t planes,
+                                    int64_t planes_g, int hw, double* block_partial, float* dscale_sample) {
+    if ((hw & 3) != 0 || hw > 128 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) != 0) return false;
+    const int q4 = hw >> 2;
+#define NORM_SMALL(LPV) norm_bwd_plane_small_kernel<ACT, LPV><<<blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, \
+        planes, planes_g, hw, block_partial, dscale_sample)
+    if (q4 <= 1) NORM_SMALL(1);
+    else if (q4 <= 2) NORM_SMALL(2);
+    else if (q4 <= 4) NORM_SMALL(4);
+    else if (q4 <= 8) NORM_SMALL(8);
+    else if (q4 <= 16) NORM_SMALL(16);
+    else NORM_SMALL(32);
+    return true;
+}
+
 // Deterministic (fixed summation order - no atomics - so that eager and hipGraph replays agree bit for bit).
 // Block = 16 channels x 16 batch slots; the slots meet through LDS in a fixed order.  Per block and group the partial
 // sums of y*S1 and y*S2 go to `partial` [blocks][NORM_MAX_GROUPS][2] (double); the dx kernel adds them up.
@@ -417,7 +505,10 @@ LOCATE_API int locate_norm_bwd(const float* x, const float* g, const float* stat
     int64_t blocks = cdiv64(planes, 4);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = as_stream(stream);
-    if (with_act)
+    const bool small = with_act ? launch_norm_plane_small<true>((int)blocks, st, x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr)
+                                : launch_norm_plane_small<false>((int)blocks, st, x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr);
+    if (small) {
+    } else if (with_act)
         norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr);
     else
         norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, nullptr, nullptr);
@@ -464,7 +555,10 @@ LOCATE_API int locate_norm_bwd_fused(const float* x, const float* g, const float
     int64_t blocks = cdiv64(planes, 4);
     if (blocks > NBF_BLOCKS) blocks = NBF_BLOCKS;
     hipStream_t st = as_stream(stream);
-    if (with_act)
+    const bool small = with_act ? launch_norm_plane_small<true>((int)blocks, st, x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample)
+                                : launch_norm_plane_small<false>((int)blocks, st, x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample);
+    if (small) {
+    } else if (with_act)
         norm_bwd_plane_kernel<true><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample);
     else
         norm_bwd_plane_kernel<false><<<(int)blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw, partial, dscale_sample);

@@ -100,7 +100,11 @@ def test_inplace_norm_fused_activation_and_big():
     from locate_amd import ops
     from oracle import locate_oracle as O
     torch.manual_seed(11)
-    for shape, per_sample in (((4, 6, 5, 7), False), ((8, 48, 64, 64), True), ((64, 768, 2, 2), True), ((3, 5, 1, 1), False)):
+    # (the 2x2 ... 8x8 planes take the several-planes-per-wave backward, norm_bwd_plane_small_kernel: one to 32 lanes per plane,
+    # plane counts that do not fill the last wave)
+    for shape, per_sample in (((4, 6, 5, 7), False), ((8, 48, 64, 64), True), ((64, 768, 2, 2), True), ((3, 5, 1, 1), False),
+                              ((5, 7, 2, 4), False), ((6, 33, 4, 4), True), ((3, 11, 6, 6), False), ((7, 13, 8, 8), True),
+                              ((2, 9, 8, 16), False)):
         B, C = shape[:2]
         x = torch.randn(shape) * 1.7 + 0.4
         y = torch.randn(B if per_sample else 1, C, 1, 1)
@@ -138,7 +142,10 @@ def test_residual_gate_large_vs_oracle():
     from locate_amd import ops
     from oracle import locate_oracle as O
     torch.manual_seed(5)
-    for shape, bc in (((64, 48, 64, 64), False), ((64, 192, 16, 16), True), ((8, 512, 1, 1), False)):
+    # (planes of 4 ... 128 elements: gate_bwd_small_kernel, one to 32 lanes per plane)
+    for shape, bc in (((64, 48, 64, 64), False), ((64, 192, 16, 16), True), ((8, 512, 1, 1), False), ((48, 512, 2, 2), True),
+                      ((5, 7, 2, 2), False), ((6, 33, 4, 4), True), ((3, 11, 6, 6), False), ((7, 13, 8, 8), True), ((2, 9, 8, 16), False),
+                      ((9, 5, 2, 4), True)):
         x = torch.randn(shape)
         a = torch.randn(shape[0], shape[1], 1, 1) if bc else torch.randn(shape)
         gamma = torch.tensor([[3.0]])
