@@ -145,7 +145,7 @@ def test_residual_gate_large_vs_oracle():
     # (planes of 4 ... 128 elements: gate_bwd_small_kernel, one to 32 lanes per plane)
     for shape, bc in (((64, 48, 64, 64), False), ((64, 192, 16, 16), True), ((8, 512, 1, 1), False), ((48, 512, 2, 2), True),
                       ((5, 7, 2, 2), False), ((6, 33, 4, 4), True), ((3, 11, 6, 6), False), ((7, 13, 8, 8), True), ((2, 9, 8, 16), False),
-                      ((9, 5, 2, 4), True)):
+                      ((9, 5, 2, 4), True), ((64, 512, 1, 1), True), ((3, 64, 1, 1), True)):
         x = torch.randn(shape)
         a = torch.randn(shape[0], shape[1], 1, 1) if bc else torch.randn(shape)
         gamma = torch.tensor([[3.0]])
