@@ -526,10 +526,12 @@ LOCATE_API int locate_gate_bwd(const float* x, const float* a, int a_per_plane, 
     LOCATE_REQUIRE(planes > 0 && hw > 0 && workspace, "locate_gate_bwd: bad shape or missing workspace");
     double* block_x2g = static_cast<double*>(workspace);
     const int64_t blocks = gate_bwd_blocks(planes, hw);          // (what the caller sized its partial sums for)
-    if (hw == 1 && a_per_plane && (planes & 63) == 0) {
-        // a 1x1 map with one gate value per plane IS the element-wise form (a, da: [planes]) over "planes" of 64 values each: the
-        // several-planes-per-wave kernel instead of one wave per single element (25 us for the 98 304 values of the deepest block)
-        planes >>= 6; hw = 64; a_per_plane = 0; da_absmax = nullptr;
+    if (hw == 1 && (planes & 63) == 0) {
+        // a 1x1 map (either form of the gate value: a, da are [planes] both ways) IS the element-wise form over "planes" of 64
+        // values each: the several-planes-per-wave kernel instead of one wave per single element (25 us for the 98 304 values of
+        // the deepest block)
+        if (a_per_plane) { a_per_plane = 0; da_absmax = nullptr; }
+        planes >>= 6; hw = 64;
     }
     const bool whole_block = hw >= 1024;
     const bool vec = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |

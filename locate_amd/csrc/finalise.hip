@@ -101,9 +101,25 @@ __global__ void __launch_bounds__(256) fin_sn_rank1_kernel(const FinBatch batch,
     }
     const int64_t n = (int64_t)h * wd;
     const int64_t stride = (int64_t)nblk * blockDim.x;
-    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
-        gw[i] = fmaf(total * u[r], v[c], gw[i]);
+    if ((wd & 3) == 0 && n < (1ll << 33) && ((reinterpret_cast<uintptr_t>(gw) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        // 16-byte accesses, one 32-bit division per four elements (the scalar loop below pays a 64-bit division per element:
+        // 49 us for the discriminator's 47 MB of weight gradients, 2 TB/s); the same fma per element
+        const unsigned wd4 = (unsigned)(wd >> 2);
+        const float4* v4p = reinterpret_cast<const float4*>(v);
+        float4* g4p = reinterpret_cast<float4*>(gw);
+        for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+            const unsigned r = (unsigned)i / wd4, c4 = (unsigned)i - r * wd4;
+            const float tu = total * u[r];
+            const float4 vv = v4p[c4];
+            float4 gv = g4p[i];
+            gv.x = fmaf(tu, vv.x, gv.x); gv.y = fmaf(tu, vv.y, gv.y); gv.z = fmaf(tu, vv.z, gv.z); gv.w = fmaf(tu, vv.w, gv.w);
+            g4p[i] = gv;
+        }
+    } else {
+        for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int r = (int)(i / wd), c = (int)(i - (int64_t)r * wd);
+            gw[i] = fmaf(total * u[r], v[c], gw[i]);
+        }
     }
     if (bx == 0) {
         if (du) {

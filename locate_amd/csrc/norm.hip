@@ -281,12 +281,14 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_small_kernel(const float* 
                                                                    int64_t planes_g, int hw, double* __restrict__ block_partial,
                                                                    float* __restrict__ dscale_sample) {
     __shared__ double bp[4][NORM_MAX_GROUPS][2];
-    constexpr int PW = 64 / LP;
+    // LP == 0: planes of ONE or TWO elements (1x1 maps) - a lane per plane, scalar accesses
+    constexpr int LPE = LP == 0 ? 1 : LP;
+    constexpr int PW = 64 / LPE;
     double acc_a[NORM_MAX_GROUPS], acc_b[NORM_MAX_GROUPS];
 #pragma unroll
     for (int q = 0; q < NORM_MAX_GROUPS; ++q) acc_a[q] = acc_b[q] = 0.0;
     const int lane = threadIdx.x & 63;
-    const int gid = lane / LP, li = lane % LP;
+    const int gid = lane / LPE, li = lane % LPE;
     const int q4 = hw >> 2;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -300,7 +302,16 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_small_kernel(const float* 
         const float yv = (ACT || block_partial != nullptr) ? scale[scale_per_sample ? pp : c] : 0.0f;
         const float y = ACT ? yv : 0.0f, b = ACT ? bias[c] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
-        if (live && li < q4) {
+        if constexpr (LP == 0) {
+            if (live) {
+                for (int i = 0; i < hw; ++i) {          // (hw <= 2: e0 + e1, the wave-per-plane kernel's own order)
+                    const float xv = x[pp * hw + i];
+                    const float gv = norm_go<ACT>(xv, g[pp * hw + i], mu, inv_sd, y, b);
+                    s1 += gv;
+                    s2 = i == 0 ? (xv - mu) * gv : fmaf(xv - mu, gv, s2);
+                }
+            }
+        } else if (live && li < q4) {
             const float4 xv = reinterpret_cast<const float4*>(x + pp * hw)[li];
             float4 gv = reinterpret_cast<const float4*>(g + pp * hw)[li];
             gv.x = norm_go<ACT>(xv.x, gv.x, mu, inv_sd, y, b); gv.y = norm_go<ACT>(xv.y, gv.y, mu, inv_sd, y, b);
@@ -309,7 +320,7 @@ __global__ void __launch_bounds__(256) norm_bwd_plane_small_kernel(const float* 
             s2 = ((xv.x - mu) * gv.x + (xv.y - mu) * gv.y) + ((xv.z - mu) * gv.z + (xv.w - mu) * gv.w);
         }
 #pragma unroll
-        for (int o = LP / 2; o > 0; o >>= 1) {
+        for (int o = LPE / 2; o > 0; o >>= 1) {
             s1 += __shfl_xor(s1, o, 64);
             s2 += __shfl_xor(s2, o, 64);
         }
@@ -346,6 +357,11 @@ template <bool ACT>
 static bool launch_norm_plane_small(int blocks, hipStream_t st, const float* x, const float* g, const float* stats, const float* scale,
                                     int scale_per_sample, const float* bias, int C, float* S1, float* S2, int64_t planes,
                                     int64_t planes_g, int hw, double* block_partial, float* dscale_sample) {
+    if (hw == 1) {
+        norm_bwd_plane_small_kernel<ACT, 0><<<blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, planes, planes_g, hw,
+                                                                   block_partial, dscale_sample);
+        return true;
+    }
     if ((hw & 3) != 0 || hw > 128 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) != 0) return false;
     const int q4 = hw >> 2;
 #define NORM_SMALL(LPV) norm_bwd_plane_small_kernel<ACT, LPV><<<blocks, 256, 0, st>>>(x, g, stats, scale, scale_per_sample, bias, C, S1, S2, \

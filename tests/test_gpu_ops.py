@@ -104,7 +104,7 @@ def test_inplace_norm_fused_activation_and_big():
     # plane counts that do not fill the last wave)
     for shape, per_sample in (((4, 6, 5, 7), False), ((8, 48, 64, 64), True), ((64, 768, 2, 2), True), ((3, 5, 1, 1), False),
                               ((5, 7, 2, 4), False), ((6, 33, 4, 4), True), ((3, 11, 6, 6), False), ((7, 13, 8, 8), True),
-                              ((2, 9, 8, 16), False)):
+                              ((2, 9, 8, 16), False), ((96, 64, 1, 1), True), ((7, 33, 1, 1), False)):
         B, C = shape[:2]
         x = torch.randn(shape) * 1.7 + 0.4
         y = torch.randn(B if per_sample else 1, C, 1, 1)

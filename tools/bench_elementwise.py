@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="64: the step's own tensors (48-100 MB: they fit the 256 MB Infinity Cache between producer and consumer); 256: "
                          "192-400 MB per operand - every pass really goes to HBM")
+    ap.add_argument("--all-shapes", action="store_true", help="every activation shape of the config-2 step instead of the three largest")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = lib()
@@ -41,14 +42,23 @@ def main():
 
     def report(name, shape, fwd, bwd, fe, be):
         tf, tb = time_it(fwd, args.reps), time_it(bwd, args.reps)
-        print("%-30s %-16s %9.4f | %6.0f | %4.2f     %9.4f | %6.0f | %4.2f" % (
+        # x model: time against 3 us + bytes at 5 TB/s (what a well-distributed streaming kernel takes on this chip)
+        mf, mb = tf / (3e-6 + 4 * fe / 5e12), tb / (3e-6 + 4 * be / 5e12)
+        print("%-30s %-16s %9.4f | %6.0f | %4.2f     %9.4f | %6.0f | %4.2f   x model %4.1f %4.1f%s" % (
             name, "x".join(map(str, shape)), tf * 1e3, 4 * fe / tf / 1e9, 4 * fe / tf / PEAK, tb * 1e3, 4 * be / tb / 1e9,
-            4 * be / tb / PEAK), flush=True)
+            4 * be / tb / PEAK, mf, mb, "  <<<" if max(mf, mb) > 2.0 else ""), flush=True)
 
     def P(t):
         return t.data_ptr()
 
-    for shape in ((B, 96, 64, 64), (B, 48, 64, 64), (B, 192, 16, 16)):
+    shapes = ((B, 96, 64, 64), (B, 48, 64, 64), (B, 192, 16, 16))
+    if args.all_shapes:
+        # every activation shape of the step (generator at batch B, discriminator at the stacked 3 B): the small and mid-sized maps are
+        # where a kernel's work distribution, not the memory system, decides its time
+        shapes = ((B, 768, 4, 4), (B, 768, 8, 8), (B, 384, 8, 8), (B, 384, 16, 16), (B, 192, 16, 16), (B, 192, 32, 32), (B, 96, 32, 32),
+                  (B, 96, 64, 64), (B, 48, 64, 64), (3 * B, 32, 32, 32), (3 * B, 64, 16, 16), (3 * B, 128, 8, 8), (3 * B, 256, 4, 4),
+                  (3 * B, 512, 2, 2), (3 * B, 512, 1, 1))
+    for shape in shapes:
         Bn, C, H, W = shape
         hw, planes = H * W, Bn * C
         n = planes * hw
@@ -76,7 +86,9 @@ def main():
                lambda: check(L.locate_gate_bwd(P(x), P(ac), 1, P(gam), P(g), P(gx), P(dac), P(dgam), planes, hw, P(ws_g), 0, None, st)), 2 * n, 3 * n)
         report("softmax over H*W", shape, lambda: check(L.locate_softmax_fwd(P(x), P(y), planes, hw, st)),
                lambda: check(L.locate_softmax_bwd(P(y), P(g), P(gx), planes, hw, st)), 2 * n, 3 * n)
-        if H == 64:
+        if H == 1:
+            continue
+        if H == 64 or (args.all_shapes and shape[0] != B):
             q = torch.empty(Bn, C, H // 2, W // 2, device=dev)
             gq = torch.randn_like(q)
             report("avgpool 2x2", shape, lambda: check(L.locate_avgpool2_fwd(P(x), P(q), planes, H, W, st)),
