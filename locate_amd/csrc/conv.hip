@@ -2455,57 +2455,86 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p
 // the block emits one partial of <G_k / sigma_k, W_bar> PER CALL (partial[k * nblocks + bid]) - what the spectral-norm backward
 // of stacked calls needs for d(sigma_k), from slab values this pass reads anyway (the activation-side dots <gy_k, y_k - b>
 // it replaces read both activations of every layer once more).
-template <int ZP>
+// V = 4: four consecutive elements per thread (16-byte accesses, n % 4 == 0) - the same additions per element in the same order
+// as V = 1 (whose 4-byte accesses in 64-byte runs reached 1.5 TB/s on the 150 MB of a generator pass's slabs).
+template <int V>
+__device__ __forceinline__ void slab_load(const float* p, float (&v)[V]) {
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else v[0] = *p;
+}
+
+template <int ZP, int V>
 __device__ __forceinline__ void slab_reduce_groups(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
                                                    const float* __restrict__ w_ref, double* __restrict__ partial, int bid, int nblocks,
-                                                   int groups, int zper) {
-    __shared__ double gscratch[16];
-    __shared__ float gzsum[4][ZP][256 / ZP];
-    constexpr int EPB = 256 / ZP;
-    const int ex = threadIdx.x % EPB, ez = threadIdx.x / EPB;
+                                                   int groups, int zper, float* zbuf, double* gscratch) {
+    float (*gzsum)[ZP][256 / ZP][V] = reinterpret_cast<float (*)[ZP][256 / ZP][V]>(zbuf);          // [4][ZP][256 / ZP][V]
+    constexpr int TPB = 256 / ZP, EPB = TPB * V;
+    const int ex = threadIdx.x % TPB, ez = threadIdx.x / TPB;
     const int64_t stride = (int64_t)nblocks * EPB;
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t i0 = (int64_t)bid * EPB; i0 < n; i0 += stride) {
-        const int64_t i = i0 + ex;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int64_t i = i0 + V * ex;
+        float acc[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[k][e] = 0.0f;
         if (i < n) {
             // z walks ALL slabs, call-major, eight loads in flight; slab z belongs to call z / zper and is added to that call's sum
             // (the other calls' sums take + 0.0f: exact), in z order within each call
             const float* __restrict__ sp = slab + i;
             for (int z = ez; z < nsplit; z += 8 * ZP) {
-                float v[8];
+                float v[8][V];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < nsplit ? sp[(int64_t)(z + q * ZP) * n] : 0.0f;
+                for (int q = 0; q < 8; ++q) {
+                    if (z + q * ZP < nsplit) slab_load<V>(sp + (int64_t)(z + q * ZP) * n, v[q]);
+                    else
+#pragma unroll
+                        for (int e = 0; e < V; ++e) v[q][e] = 0.0f;
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int zz = z + q * ZP;
                     const int k = (zz >= zper) + (zz >= 2 * zper) + (zz >= 3 * zper);
-                    acc[0] += k == 0 ? v[q] : 0.0f;
-                    acc[1] += k == 1 ? v[q] : 0.0f;
-                    acc[2] += k == 2 ? v[q] : 0.0f;
-                    acc[3] += k == 3 ? v[q] : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        acc[0][e] += k == 0 ? v[q][e] : 0.0f;
+                        acc[1][e] += k == 1 ? v[q][e] : 0.0f;
+                        acc[2][e] += k == 2 ? v[q][e] : 0.0f;
+                        acc[3][e] += k == 3 ? v[q][e] : 0.0f;
+                    }
                 }
             }
         }
         if (ZP > 1) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gzsum[k][ez][ex] = acc[k];
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) gzsum[k][ez][ex][e] = acc[k][e];
             __syncthreads();
             if (ez == 0)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a = 0.0f;
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int g = 0; g < ZP; ++g) a += gzsum[k][g][ex];
-                    acc[k] = a;
-                }
+                    for (int e = 0; e < V; ++e) {
+                        float a = 0.0f;
+#pragma unroll
+                        for (int g = 0; g < ZP; ++g) a += gzsum[k][g][ex][e];
+                        acc[k][e] = a;
+                    }
         }
         if (ez == 0 && i < n) {
-            const double w = w_ref ? (double)w_ref[i] : 0.0;
+            float o[V];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dot[k] += (double)acc[k] * w;
-            out[i] = ((acc[0] + acc[1]) + acc[2]) + acc[3];          // calls beyond `groups` contribute + 0.0f: exact
+            for (int e = 0; e < V; ++e) {
+                const double w = w_ref ? (double)w_ref[i + e] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dot[k] += (double)acc[k][e] * w;
+                o[e] = ((acc[0][e] + acc[1][e]) + acc[2][e]) + acc[3][e];          // calls beyond `groups` contribute + 0.0f: exact
+            }
+            if constexpr (V == 4) *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+            else out[i] = o[0];
         }
     }
     if (partial) {
@@ -2516,47 +2545,64 @@ __device__ __forceinline__ void slab_reduce_groups(const float* __restrict__ sla
     }
 }
 
-template <int ZP>
-__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
-                                                 const float* __restrict__ w_ref, const float* __restrict__ inv_scale,
-                                                 double* __restrict__ partial, int bid, int nblocks, int groups = 0, int zper = 0) {
+template <int ZP, int V>
+__device__ __forceinline__ void slab_reduce_body_v(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
+                                                   const float* __restrict__ w_ref, const float* __restrict__ inv_scale,
+                                                   double* __restrict__ partial, int bid, int nblocks, int groups, int zper,
+                                                   float* zbuf, double* scratch) {
     if (groups > 1) {
-        slab_reduce_groups<ZP>(slab, out, n, nsplit, w_ref, partial, bid, nblocks, groups, zper);
+        slab_reduce_groups<ZP, V>(slab, out, n, nsplit, w_ref, partial, bid, nblocks, groups, zper, zbuf, scratch);
         return;
     }
-    __shared__ double scratch[16];
-    __shared__ float zsum[ZP][256 / ZP];
+    float (*zsum)[256 / ZP][V] = reinterpret_cast<float (*)[256 / ZP][V]>(zbuf);          // [ZP][256 / ZP][V]
     const float sc = inv_scale ? inv_scale[0] : 1.0f;
-    constexpr int EPB = 256 / ZP;                       // elements per block pass
-    const int ex = threadIdx.x % EPB, ez = threadIdx.x / EPB;
+    constexpr int TPB = 256 / ZP, EPB = TPB * V;        // threads / elements per block pass
+    const int ex = threadIdx.x % TPB, ez = threadIdx.x / TPB;
     const int64_t stride = (int64_t)nblocks * EPB;
     double dot = 0.0;
     for (int64_t i0 = (int64_t)bid * EPB; i0 < n; i0 += stride) {
-        const int64_t i = i0 + ex;
-        float acc = 0.0f;
+        const int64_t i = i0 + V * ex;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.0f;
         if (i < n) {
             // eight slabs' loads in flight, added in z order
             const float* __restrict__ sp = slab + i;
             for (int z = ez; z < nsplit; z += 8 * ZP) {
-                float v[8];
+                float v[8][V];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = z + q * ZP < nsplit ? sp[(int64_t)(z + q * ZP) * n] : 0.0f;
+                for (int q = 0; q < 8; ++q) {
+                    if (z + q * ZP < nsplit) slab_load<V>(sp + (int64_t)(z + q * ZP) * n, v[q]);
+                    else
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc += v[q];      // + 0.0f beyond nsplit: exact
+                        for (int e = 0; e < V; ++e) v[q][e] = 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += v[q][e];      // + 0.0f beyond nsplit: exact
             }
         }
         if (ZP > 1) {
             __syncthreads();
-            zsum[ez][ex] = acc;
+#pragma unroll
+            for (int e = 0; e < V; ++e) zsum[ez][ex][e] = acc[e];
             __syncthreads();
-            acc = 0.0f;
             if (ez == 0)
 #pragma unroll
-                for (int g = 0; g < ZP; ++g) acc += zsum[g][ex];
+                for (int e = 0; e < V; ++e) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < ZP; ++g) a += zsum[g][ex][e];
+                    acc[e] = a;
+                }
         }
         if (ez == 0 && i < n) {
-            if (w_ref) dot += (double)acc * (double)w_ref[i];
-            out[i] = acc * sc;
+            if (w_ref)
+#pragma unroll
+                for (int e = 0; e < V; ++e) dot += (double)acc[e] * (double)w_ref[i + e];
+            if constexpr (V == 4) *reinterpret_cast<float4*>(out + i) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
+            else out[i] = acc[0] * sc;
         }
     }
     if (partial) {
@@ -2566,7 +2612,25 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab,
 }
 
 template <int ZP>
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int nsplit,
+                                                 const float* __restrict__ w_ref, const float* __restrict__ inv_scale,
+                                                 double* __restrict__ partial, int bid, int nblocks, int groups = 0, int zper = 0) {
+    // one LDS area for whichever form runs: [4 calls][256 threads][4 values]
+    __shared__ __attribute__((aligned(16))) float zbuf[4 * 256 * 4];
+    __shared__ double scratch[16];
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    // (ZP = 16 - a handful of elements under hundreds of slabs - stays scalar: its sixteen-way LDS sums times four values spill)
+    if constexpr (ZP <= 4) {
+        if (vec) {
+            slab_reduce_body_v<ZP, 4>(slab, out, n, nsplit, w_ref, inv_scale, partial, bid, nblocks, groups, zper, zbuf, scratch);
+            return;
+        }
+    }
+    slab_reduce_body_v<ZP, 1>(slab, out, n, nsplit, w_ref, inv_scale, partial, bid, nblocks, groups, zper, zbuf, scratch);
+}
+
+template <int ZP>
+__global__ void __launch_bounds__(256, 4) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
                                                           int nsplit, const float* __restrict__ w_ref,
                                                           const float* __restrict__ inv_scale, double* __restrict__ partial,
                                                           int groups, int zper) {
@@ -2587,7 +2651,7 @@ struct SlabBatch {
     SlabRec r[SLAB_MAX];
 };
 
-__global__ void __launch_bounds__(256) slab_reduce_batch_kernel(const SlabBatch b, int nrec) {
+__global__ void __launch_bounds__(256, 4) slab_reduce_batch_kernel(const SlabBatch b, int nrec) {
     int k = 0;
     for (int i = 1; i < nrec; ++i)
         if ((int)blockIdx.x >= b.r[i].block0) k = i;          // block0 ascending
