@@ -2670,7 +2670,8 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
     if (groups > 1) {
         const int64_t Ng = (int64_t)(g.B / groups) * g.OH * g.OW;
-        const int64_t max_split = Ng >= 512 ? Ng / 256 : 1;
+        const int wg_min = knob_int("LOCATE_WG_MIN_CHUNK", 64);
+        const int64_t max_split = Ng >= 2 * wg_min ? Ng / wg_min : 1;
         int64_t best_s = 1;
         double best_cost = 1e300;
         for (int64_t s_ = 1; s_ <= max_split && s_ * groups <= 512; ++s_) {
@@ -2694,7 +2695,11 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
     // Split the reduction over s blocks per tile so that the launch fills whole rounds of the 768 resident blocks
     // (256 CUs x 3): cost(s) = rounds(s) x reduction elements per block, plus the slab traffic of s > 1 expressed in
     // the same unit (one output tile written and re-read ~ 96 reduction elements of MFMA time).
-    const int64_t max_split = N >= 512 ? N / 256 : 1;     // at least 256 reduction elements per block
+    const int wg_min = knob_int("LOCATE_WG_MIN_CHUNK", 64);
+    const int64_t max_split = N >= 2 * wg_min ? N / wg_min : 1;     // at least 64 reduction elements per block (the split
+    // reductions of a pass run as ONE batched launch at its end, so a deeper split costs slab traffic only: the deep layers' 8 - 24
+    // tiles x 3 splits of 256 were latency chains of 16 steps on a tenth of the chip; same-box A/B of the step: 256 -> 9.13 / 9.12,
+    // 128 -> 9.06 / 9.05, 64 -> 9.05 / 9.03, 32 -> 9.06 / 9.06 ms)
     int64_t best_s = 1;
     double best_cost = 1e300;
     for (int64_t s_ = 1; s_ <= max_split && s_ <= 512; ++s_) {
