@@ -325,8 +325,37 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
                         const float v = stage[nl * 33 + ml];
                         if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
                     }
+                } else if (TM * TN <= 2 && p.mul_pre != nullptr) {
+                    // the fused forms (see below).  (Instantiations with few tiles per wave - the ones small maps are launched
+                    // with; the large tiles' register budget has no room for this and takes the rolled loop at the end.)
+                    // The sixteen pre-activation loads of the tile go out together (one after the other
+                    // they were sixteen exposed round trips: 33 us for a 16-block launch that takes 17 without the epilogue); the
+                    // fences keep the compiler from hoisting every tile's loads to the top (the tall tiles then spill)
+                    __builtin_amdgcn_sched_barrier(0);
+                    float z[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int flat = e * 64 + lane;
+                        const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
+                        const int ml = rem >> lp, pix = rem & (iplane - 1);
+                        const int nl = (bl << lp) + pix;
+                        const bool ok = nt0 + nl < N && mt0 + ml < p.M;
+                        z[e] = ok ? p.mul_pre[(long long)(b0 + bl) * p.mul_bs + (long long)(mt0 + ml) * plane + pix] : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int flat = e * 64 + lane;
+                        const int bl = flat >> (5 + lp), rem = flat & ((32 << lp) - 1);
+                        const int ml = rem >> lp, pix = rem & (iplane - 1);
+                        const int nl = (bl << lp) + pix;
+                        if (nt0 + nl < N && mt0 + ml < p.M) {
+                            const float v = roottanh_grad_f(z[e], stage[nl * 33 + ml]);
+                            am_s = fmaxf(am_s, fabsf(v));
+                            out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 } else {
-                    // the fused forms (see below): a rolled loop - the values come from the LDS patch, not from the accumulators
 #pragma unroll 1
                     for (int e = 0; e < 16; ++e) {
                         const int flat = e * 64 + lane;
