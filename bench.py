@@ -44,11 +44,11 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--wgrad-overlap", choices=("auto", "on", "off"), default="auto",
                     help="weight gradients on a second stream beside the backward pass's chain of input gradients (same values; the "
-                         "data-parallel reducer picks such gradients up at the end of the pass - tests/test_gpu_dp.py).  auto: off on "
-                         "one GPU - since the small weight gradients and all split reductions of a pass run as two batched launches at "
-                         "its end, the ~60 forks into the second stream cost more than the concurrency returns (same-box A/B, "
-                         "profiles/r03_wgrad_overlap_ab.txt: 9.88 -> 9.72 ms) - and on in the data-parallel mode, whose reducer hooks "
-                         "keep the per-layer finalisers")
+                         "data-parallel reducer picks such gradients up at the end of the pass - tests/test_gpu_dp.py).  auto = off: "
+                         "since the small weight gradients and all split reductions of a pass run as two batched launches at its end, "
+                         "the ~60 forks into the second stream cost more than the concurrency returns (same-box A/B, "
+                         "profiles/r03_wgrad_overlap_ab.txt: 9.88 -> 9.72 ms; in the one-rank RCCL rehearsal of round 4 9.91 / 9.85 "
+                         "on, 9.68 / 9.71 off)")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="same as --wgrad-overlap off")
     ap.add_argument("--f16-min-gflop", type=float, default=None,
                     help="work threshold (GFLOP per launch) above which a fp32-faithful contraction takes its fp16-piece form "
@@ -328,7 +328,7 @@ def main():
         red_g = GradAllReducer(G.parameters(), force=force_dp, solo_bytes=solo, bucket_bytes=bucket)
         red_d = GradAllReducer(D.parameters(), late=late_v, groups=D.segment_parameters(d_cut) if d_cut else None, force=force_dp,
                                solo_bytes=solo, bucket_bytes=bucket)
-    wgrad_overlap = False if (args.no_wgrad_overlap or args.wgrad_overlap == "off") else (True if args.wgrad_overlap == "on" else bool(dp))
+    wgrad_overlap = args.wgrad_overlap == "on" and not args.no_wgrad_overlap
     step = TrainStep(G, D, GO, DO, reducer_g=red_g, reducer_d=red_d, concurrent_d=args.concurrent_d,
                      overlap_wgrad=wgrad_overlap, d_cut=d_cut)
     B, S = args.batch, args.image_size

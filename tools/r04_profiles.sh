@@ -29,6 +29,7 @@ python tools/bench_conv.py --f16 --check > $O/conv_microbench_f16.txt 2>&1
 python tools/bench_conv.py --f16 --win --check > $O/conv_microbench_f16_window.txt 2>&1
 python tools/bench_conv.py --check > $O/conv_microbench_bf16x6.txt 2>&1
 python tools/layer_table.py > $O/layer_table.txt 2>&1
+python tools/bench_elementwise.py --all-shapes > $O/elementwise_all_shapes.txt 2>&1
 python tools/amax_overhead.py > $O/amax_overhead.txt 2>&1
 rm -rf $O/trace $O/pmc_f $O/pmc_w $O/pmc_sq $O/ew_f64 $O/ew_f256 $O/ew_w64 $O/ew_w256 2>/dev/null
 ls $O
