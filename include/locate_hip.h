@@ -223,6 +223,8 @@ int locate_conv_dgrad(const int* geom, const float* gy, int64_t gy_bs, const flo
  * of <UNSCALED gw, W_bar>, which the spectral-norm backward needs; inv_scale, w_ref, inner_partial are nullable.
  * scale_group_batch > 0: gy of batch element b is weighted by inv_scale[(b / scale_group_batch) * scale_stride] instead
  * (gw = sum_k G_k / sigma_k over stacked forward calls; <= 4 groups; w_ref and inner_partial must be null). */
+/* (layers with M % 192 == 0 on maps with even OH * OW and OW run on 192 x 128 tiles of the paired-load kernels only: gy must then
+ * be 8-byte aligned with an even batch stride - any contiguous tensor is) */
 size_t locate_conv_wgrad_workspace_bytes(const int* geom);
 int locate_conv_wgrad_partials(const int* geom);
 /* deferred_reduce (nullable; host memory, locate_slab_reduce_record_bytes() bytes): the split reduction of this launch is not

@@ -2208,7 +2208,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgParams p) {
 // n of one row / column); lane (r, h) reads the 8 bytes k = 8h .. 8h + 7, the two halves swapped on rows with bit 4 set (conflict-free
 // ds_read_b64 over 32 rows); a thread's pair goes in as one 16-bit store.
 template <int WGM, int WGN, int TM, int TN, int NP>       // NP = 3: exact splits; NP = 1: bf16 operands; NP = 2: two scaled fp16 pieces (see conv_igemm_bx6_kernel)
-__global__ void __launch_bounds__(256, 3) conv_wgrad_bx6_kernel(const WgParams p) {
+__global__ void __launch_bounds__(256, (WGM * TM > 4 ? 2 : 3)) conv_wgrad_bx6_kernel(const WgParams p) {
     constexpr int BM = WGM * TM * 32;
     constexpr int BR = WGN * TN * 32;
     constexpr int G_PT = BM / 32;          // row groups per thread: rows sub + 32 i
@@ -2667,6 +2667,10 @@ __global__ void __launch_bounds__(256, 4) slab_reduce_batch_kernel(const SlabBat
 static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int* tiles_out, int groups = 0, int* zper_out = nullptr) {
     *bm = pick_bm(g.M);
     const int R = g.C * g.KH * g.KW;
+    // tall 192 x 128 tiles (96 x 64 per wave: a third more MFMAs per gathered and split element, two blocks per CU) for the wide
+    // layers, as in the forward kernels (same-box A/B of the step: 9.031 / 9.039 -> 9.010 / 8.997 ms); paired-load kernels only
+    if (g.M % 192 == 0 && ((g.OH * g.OW) & 1) == 0 && (g.OW & 1) == 0 && knob_int("LOCATE_WG_TALL", 1) && !path_disabled("wbx6") && (int64_t)(g.M / 192) * ((R + 127) / 128) >= knob_int("LOCATE_WG_TALL_MIN_TILES", 24)) *bm = 192;
+    const int64_t slots = *bm == 192 ? 512 : 768;
     const int64_t tiles = (int64_t)((g.M + *bm - 1) / *bm) * ((R + 127) / 128);
     if (groups > 1) {
         const int64_t Ng = (int64_t)(g.B / groups) * g.OH * g.OW;
@@ -2678,8 +2682,8 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
             int64_t ch = (Ng + s_ - 1) / s_;
             ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
             const int64_t ns = groups * ((Ng + ch - 1) / ch);
-            const int64_t rounds = (tiles * ns + 767) / 768;
-            const double cost = (double)rounds * (double)ch + 96.0 * (double)ns * (double)tiles / 768.0;
+            const int64_t rounds = (tiles * ns + slots - 1) / slots;
+            const double cost = (double)rounds * (double)ch + 96.0 * (double)ns * (double)tiles / (double)slots;
             if (cost < best_cost * 0.999) { best_cost = cost; best_s = s_; }
         }
         int64_t ch = (Ng + best_s - 1) / best_s;
@@ -2706,8 +2710,8 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
         int64_t ch = (N + s_ - 1) / s_;
         ch = (ch + WG_BK - 1) / WG_BK * WG_BK;
         const int64_t ns = (N + ch - 1) / ch;
-        const int64_t rounds = (tiles * ns + 767) / 768;
-        const double cost = (double)rounds * (double)ch + (ns > 1 ? 96.0 * (double)ns * (double)tiles / 768.0 : 0.0);
+        const int64_t rounds = (tiles * ns + slots - 1) / slots;
+        const double cost = (double)rounds * (double)ch + (ns > 1 ? 96.0 * (double)ns * (double)tiles / (double)slots : 0.0);
         if (cost < best_cost * 0.999) { best_cost = cost; best_s = s_; }
     }
     int64_t ch = (N + best_s - 1) / best_s;
@@ -3455,23 +3459,28 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
     // pairs of adjacent reduction elements: same image and same output row, 8-byte aligned in gy
     const bool pairs_ok = ((g.OH * g.OW) & 1) == 0 && (g.OW & 1) == 0 && (gy_bs & 1) == 0 && (chunk & 1) == 0 &&
                           (reinterpret_cast<uintptr_t>(gy) & 7) == 0 && x_extent > 0 && x_extent < (1ll << 31) - (1 << 20);
+    LOCATE_REQUIRE(bm != 192 || pairs_ok, "locate_conv_wgrad: layers with M %% 192 == 0 on even maps take the paired-load kernels - gy must be 8-byte aligned with an even batch stride");
     if (precision == 3 && pairs_ok) {          // (odd output maps: the exact fp32-MFMA kernel below, at every precision setting)
-        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 4><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_wgrad_bx6_kernel<2, 2, 3, 2, 4><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 4><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 4><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 4><<<grid, 256, 0, st>>>(p);
         else conv_wgrad_bx6_kernel<1, 4, 1, 1, 4><<<grid, 256, 0, st>>>(p);
     } else if (pairs_ok && precision == 1) {
-        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_wgrad_bx6_kernel<2, 2, 3, 2, 1><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 1><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 1><<<grid, 256, 0, st>>>(p);
         else conv_wgrad_bx6_kernel<1, 4, 1, 1, 1><<<grid, 256, 0, st>>>(p);
     } else if (pairs_ok && precision == 2 && !path_disabled("wbx6")) {
-        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_wgrad_bx6_kernel<2, 2, 3, 2, 2><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 2><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 2><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 2><<<grid, 256, 0, st>>>(p);
         else conv_wgrad_bx6_kernel<1, 4, 1, 1, 2><<<grid, 256, 0, st>>>(p);
     } else if (pairs_ok && !path_disabled("wbx6")) {
-        if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
+        if (bm == 192) conv_wgrad_bx6_kernel<2, 2, 3, 2, 3><<<grid, 256, 0, st>>>(p);
+        else if (bm == 128) conv_wgrad_bx6_kernel<2, 2, 2, 2, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 96) conv_wgrad_bx6_kernel<1, 4, 3, 1, 3><<<grid, 256, 0, st>>>(p);
         else if (bm == 64) conv_wgrad_bx6_kernel<1, 4, 2, 1, 3><<<grid, 256, 0, st>>>(p);
         else conv_wgrad_bx6_kernel<1, 4, 1, 1, 3><<<grid, 256, 0, st>>>(p);
