@@ -2758,6 +2758,8 @@ struct PwParams {
     int steps, chunk;          // 16-pixel steps in all, steps per wave
     int tiles_c;
     int gscale_bg, gscale_stride;
+    const unsigned* x_absmax;  // NP = 2 (two scaled fp16 pieces, three MFMAs - conv_igemm_bx6_kernel's form): largest magnitudes of
+    const unsigned* g_absmax;  // x and of gy, AMAX_WORDS words each
 };
 
 template <int TM, int TN, int NP>
@@ -2796,6 +2798,12 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
         brow[j] = (long long)(bok[j] ? c : 0) * p.P;
     }
     const DivU32 dp((unsigned)p.P);
+    float x_scale = 1.0f, g_scale = 1.0f, x_unscale = 1.0f, g_unscale = 1.0f;
+    if constexpr (NP == 2) {          // powers of two into fp16's range; the exact inverses go back in after the loop
+        const int kx = f16_scale_exp(absmax_read(p.x_absmax)), kg = f16_scale_exp(absmax_read(p.g_absmax));
+        x_scale = pow2f(kx); g_scale = pow2f(kg);
+        x_unscale = pow2f(-kx); g_unscale = pow2f(-kg);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -2840,18 +2848,24 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
     if (s_begin < s_end) load(s_begin, ca, cb, csc);
     for (int s = s_begin; s < s_end; ++s) {
         load(s + 1, na, nb, nsc);
-        bf16x8 a[TM][NP], b[TN][NP];
+        using pfrag_t = typename std::conditional<NP == 2, f16x8, bf16x8>::type;
+        pfrag_t a[TM][NP], b[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float w = aok[i] ? csc : 0.0f;
             float v[8] = {ca[i][0].x * w, ca[i][0].y * w, ca[i][0].z * w, ca[i][0].w * w,
                           ca[i][1].x * w, ca[i][1].y * w, ca[i][1].z * w, ca[i][1].w * w};
-            if constexpr (NP == 3) {
+            if constexpr (NP == 2) {
+                uint4 h, l;
+                split2_f16x8(v, g_scale, h, l);
+                a[i][0] = *reinterpret_cast<pfrag_t*>(&h);
+                a[i][NP - 1] = *reinterpret_cast<pfrag_t*>(&l);
+            } else if constexpr (NP == 3) {
                 uint4 h, m, l;
                 split3_trunc_x8(v, h, m, l);
-                a[i][0] = *reinterpret_cast<bf16x8*>(&h);
-                a[i][NP - 2] = *reinterpret_cast<bf16x8*>(&m);
-                a[i][NP - 1] = *reinterpret_cast<bf16x8*>(&l);
+                a[i][0] = *reinterpret_cast<pfrag_t*>(&h);
+                a[i][NP - 2] = *reinterpret_cast<pfrag_t*>(&m);
+                a[i][NP - 1] = *reinterpret_cast<pfrag_t*>(&l);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[i][0][e] = (__bf16)v[e];
@@ -2862,12 +2876,17 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
             const float w = (bok[j] && csc != 0.0f) ? 1.0f : 0.0f;
             float v[8] = {cb[j][0].x * w, cb[j][0].y * w, cb[j][0].z * w, cb[j][0].w * w,
                           cb[j][1].x * w, cb[j][1].y * w, cb[j][1].z * w, cb[j][1].w * w};
-            if constexpr (NP == 3) {
+            if constexpr (NP == 2) {
+                uint4 h, l;
+                split2_f16x8(v, x_scale, h, l);
+                b[j][0] = *reinterpret_cast<pfrag_t*>(&h);
+                b[j][NP - 1] = *reinterpret_cast<pfrag_t*>(&l);
+            } else if constexpr (NP == 3) {
                 uint4 h, m, l;
                 split3_trunc_x8(v, h, m, l);
-                b[j][0] = *reinterpret_cast<bf16x8*>(&h);
-                b[j][NP - 2] = *reinterpret_cast<bf16x8*>(&m);
-                b[j][NP - 1] = *reinterpret_cast<bf16x8*>(&l);
+                b[j][0] = *reinterpret_cast<pfrag_t*>(&h);
+                b[j][NP - 2] = *reinterpret_cast<pfrag_t*>(&m);
+                b[j][NP - 1] = *reinterpret_cast<pfrag_t*>(&l);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) b[j][0][e] = (__bf16)v[e];
@@ -2877,7 +2896,11 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (NP == 3) {
+                if constexpr (NP == 2) {          // smallest terms first: l h, h l, h h
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                } else if constexpr (NP == 3) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);        // l h
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][NP - 1], acc[i][j], 0, 0, 0);        // h l
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 2], b[j][NP - 2], acc[i][j], 0, 0, 0);   // m m
@@ -2893,6 +2916,14 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const PwParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) { cb[j][0] = nb[j][0]; cb[j][1] = nb[j][1]; }
         csc = nsc;
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * g_unscale) * x_unscale;
     }
     // the block's four tiles, added in wave order; wave 0 writes the slab
     if (wid > 0) {
@@ -3423,7 +3454,16 @@ LOCATE_API int locate_conv_wgrad(const int* geom, const float* x, int64_t x_bs, 
         q.inv_scale = grouped ? inv_scale : nullptr; q.gscale_bg = scale_group_batch; q.gscale_stride = scale_stride;
         const dim3 grid(pq.nslab, pq.tiles_m * pq.tiles_c);
         const int key = (pq.tm - 1) * 2 + (pq.tn - 1);
-        if (precision == 1) {
+        q.x_absmax = static_cast<const unsigned*>(x_absmax);
+        q.g_absmax = static_cast<const unsigned*>(gy_absmax);
+        if (precision == 2 && x_absmax && gy_absmax && !grouped) {
+            // (stacked calls weight gy by 1 / sigma_k while it is loaded: its largest magnitude no longer bounds the scaled value -
+            // they keep the three-piece form, which needs no range)
+            if (key == 0) pw_wgrad_kernel<1, 1, 2><<<grid, 256, 0, st>>>(q);
+            else if (key == 1) pw_wgrad_kernel<1, 2, 2><<<grid, 256, 0, st>>>(q);
+            else if (key == 2) pw_wgrad_kernel<2, 1, 2><<<grid, 256, 0, st>>>(q);
+            else pw_wgrad_kernel<2, 2, 2><<<grid, 256, 0, st>>>(q);
+        } else if (precision == 1) {
             if (key == 0) pw_wgrad_kernel<1, 1, 1><<<grid, 256, 0, st>>>(q);
             else if (key == 1) pw_wgrad_kernel<1, 2, 1><<<grid, 256, 0, st>>>(q);
             else if (key == 2) pw_wgrad_kernel<2, 1, 1><<<grid, 256, 0, st>>>(q);
