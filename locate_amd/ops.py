@@ -739,7 +739,11 @@ def fork3(x):
     times when no gradient will flow."""
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x, x
-    return Fork3Fn.apply(x)
+    a, b, c = Fork3Fn.apply(x)
+    stats = getattr(x, "_locate_stats", None)      # partial norm statistics left by x's producer (residual_gate): the norm behind
+    if stats is not None:                          # alias c would otherwise take them again with a pass of its own
+        a._locate_stats = b._locate_stats = c._locate_stats = stats
+    return a, b, c
 
 
 def _slot_of(x):
