@@ -113,7 +113,13 @@ int locate_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows,
 
 /* ---- skip-branch resampling / indexing (libs/scale.py:7-45, libs/merge.py:4-16) ---- */
 int locate_upsample2x_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);   /* bilinear, align_corners=False */
-int locate_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream); /* H, W: forward input size */
+int locate_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream);
+/* FeaturePooling(r = 2) followed by the x2 upsample - the generator's skip branch (libs/scale.py:7-16,37-38) - in ONE launch:
+ * x is the RAW tensor of 2 * planes * H * W elements (FeaturePooling averages ADJACENT FLAT elements), y: [planes, 2H, 2W];
+ * bit for bit locate_feature_pool_fwd(r = 2) + locate_upsample2x_fwd.  _bwd: the adjoint, gx = the raw gradient (accumulate != 0:
+ * added to what gx holds - the second consumer of a forked tensor, as in locate_feature_pool_bwd). */
+int locate_pool2_upsample2x_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);
+int locate_pool2_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int accumulate, void* stream); /* H, W: forward input size */
 int locate_avgpool2_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream);
 int locate_avgpool2_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int accumulate, void* stream);   /* H, W: forward input size */
 int locate_feature_pool_fwd(const float* x, float* y, int64_t n_out, int r, void* stream);         /* mean of r adjacent flat elements */

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "locate_softmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "locate_upsample2x_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "locate_upsample2x_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "locate_pool2_upsample2x_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "locate_pool2_upsample2x_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "locate_avgpool2_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "locate_avgpool2_bwd": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "locate_feature_pool_fwd": (c_i, [c_p, c_p, c_i64, c_i, c_p]),
@@ -130,7 +132,7 @@ class LocateError(RuntimeError):
 
 # bumped together with locate_abi_version() in csrc/runtime.hip whenever a prototype above changes: a stale .so that still
 # exports every NAME would otherwise be called with shifted arguments
-EXPECTED_ABI = 9
+EXPECTED_ABI = 10
 
 
 _lib = None

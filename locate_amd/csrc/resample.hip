@@ -24,6 +24,23 @@ __device__ __forceinline__ float bil_eval(float ly0, float ly1, float lx0, float
     return __fmaf_rn(ly1, bot, __fmul_rn(ly0, top));
 }
 
+// POOL (the generator's skip branch: FeaturePooling(r = 2) followed by the upsample, libs/scale.py:7-16,37-38): the kernel's input
+// element i is the mean of the RAW elements 2 i, 2 i + 1 of x - what feature_pool_fwd_kernel would have written ((0 + a) + b) * 0.5,
+// same bits - so the pooled map is never stored; the backward kernels write the pooled gradient times 0.5 to both raw elements.
+template <bool POOL>
+__device__ __forceinline__ float pool_ld(const float* __restrict__ x, int64_t i) {
+    if (!POOL) return x[i];
+    const float2 t = *reinterpret_cast<const float2*>(x + 2 * i);
+    return (t.x + t.y) * 0.5f;
+}
+template <bool POOL>
+__device__ __forceinline__ float4 pool_ld4(const float* __restrict__ x, int64_t i) {          // four consecutive elements, i % 4 == 0
+    if (!POOL) return *reinterpret_cast<const float4*>(x + i);
+    const float4 a = *reinterpret_cast<const float4*>(x + 2 * i), b = *reinterpret_cast<const float4*>(x + 2 * i + 4);
+    return make_float4((a.x + a.y) * 0.5f, (a.z + a.w) * 0.5f, (b.x + b.y) * 0.5f, (b.z + b.w) * 0.5f);
+}
+
+template <bool POOL>
 __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t planes, int H, int W) {
     const int OH = 2 * H, OW = 2 * W;
@@ -39,14 +56,16 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __rest
         float ly0, ly1, lx0, lx1;
         bil_src(oy, H, y0, y1, ly0, ly1);
         bil_src(ox, W, x0, x1, lx0, lx1);
-        const float* xp = x + (int64_t)p * H * W;
-        y[i] = bil_eval(ly0, ly1, lx0, lx1, xp[y0 * W + x0], xp[y0 * W + x1], xp[y1 * W + x0], xp[y1 * W + x1]);
+        const int64_t xb = (int64_t)p * H * W;
+        y[i] = bil_eval(ly0, ly1, lx0, lx1, pool_ld<POOL>(x, xb + y0 * W + x0), pool_ld<POOL>(x, xb + y0 * W + x1),
+                        pool_ld<POOL>(x, xb + y1 * W + x0), pool_ld<POOL>(x, xb + y1 * W + x1));
     }
 }
 
 // W even: one thread per FOUR consecutive output pixels of a row (one 16-byte store).  Outputs 4j .. 4j+3 read the input
 // columns 2j-1 .. 2j+2 (clamped) of two rows: eight L1-served loads for four results instead of sixteen for four, and a
 // quarter of the store instructions.  Same expression per element as the scalar kernel: bit-identical results.
+template <bool POOL>
 __global__ void __launch_bounds__(256) upsample2x_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  int64_t planes, int H, int W) {
     const int OH = 2 * H, OW4 = W / 2;                    // groups of four output columns per row
@@ -60,15 +79,15 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_vec_kernel(const float* __
         int y0, y1;
         float ly0, ly1;
         bil_src((int)uoy, H, y0, y1, ly0, ly1);
-        const float* r0 = x + (int64_t)p * H * W + (int64_t)y0 * W;
-        const float* r1 = x + (int64_t)p * H * W + (int64_t)y1 * W;
+        const int64_t r0 = (int64_t)p * H * W + (int64_t)y0 * W, r1 = (int64_t)p * H * W + (int64_t)y1 * W;
         float out[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int x0, x1;
             float lx0, lx1;
             bil_src(4 * (int)j + e, W, x0, x1, lx0, lx1);
-            out[e] = bil_eval(ly0, ly1, lx0, lx1, r0[x0], r0[x1], r1[x0], r1[x1]);
+            out[e] = bil_eval(ly0, ly1, lx0, lx1, pool_ld<POOL>(x, r0 + x0), pool_ld<POOL>(x, r0 + x1), pool_ld<POOL>(x, r1 + x0),
+                              pool_ld<POOL>(x, r1 + x1));
         }
         reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
     }
@@ -79,6 +98,7 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_vec_kernel(const float* __
 // instructions for sixteen results (the four-wide kernel above: eight for four; the bilinear kernels were bound by their load
 // ISSUE rate, 0.28 of the HBM peak at 64 x 64) and four 16-byte stores.  Same expression, weights and source elements per output
 // as the scalar kernel: bit-identical results.
+template <bool POOL>
 __global__ void __launch_bounds__(256) upsample2x_fwd_tile_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   int64_t planes, int H, int W) {
     const int OW = 2 * W, W4 = W / 4;
@@ -90,16 +110,17 @@ __global__ void __launch_bounds__(256) upsample2x_fwd_tile_kernel(const float* _
         dw.divmod(i, t, uj);
         dh.divmod(t, p, uk);
         const int j = (int)uj, k = (int)uk;
-        const float* xp = x + (int64_t)p * H * W;
+        const int64_t xb = (int64_t)p * H * W;
         float v[3][6];                       // v[s][c]: input row clamp(k - 1 + s), column clamp(4j - 1 + c)
         const int cl = 4 * j - 1 < 0 ? 0 : 4 * j - 1, cr = 4 * j + 4 > W - 1 ? W - 1 : 4 * j + 4;
 #pragma unroll
         for (int s2 = 0; s2 < 3; ++s2) {
             int r = k - 1 + s2;
             r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-            const float* rp = xp + (int64_t)r * W;
-            const float4 mid = *reinterpret_cast<const float4*>(rp + 4 * j);
-            v[s2][0] = rp[cl]; v[s2][1] = mid.x; v[s2][2] = mid.y; v[s2][3] = mid.z; v[s2][4] = mid.w; v[s2][5] = rp[cr];
+            const int64_t rp = xb + (int64_t)r * W;
+            const float4 mid = pool_ld4<POOL>(x, rp + 4 * j);
+            v[s2][0] = pool_ld<POOL>(x, rp + cl); v[s2][1] = mid.x; v[s2][2] = mid.y; v[s2][3] = mid.z; v[s2][4] = mid.w;
+            v[s2][5] = pool_ld<POOL>(x, rp + cr);
         }
         const bool top = k == 0, bottom = k == H - 1, left = j == 0, right = 4 * j + 3 == W - 1;
 #pragma unroll
@@ -147,8 +168,9 @@ __device__ __forceinline__ float bil_weight_to(int dst, int size, int target) {
     return w;
 }
 
+template <bool POOL>
 __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                             int64_t planes, int H, int W) {
+                                                             int64_t planes, int H, int W, int accumulate) {
     const int OH = 2 * H, OW = 2 * W;
     const unsigned n = (unsigned)(planes * H * W);
     const unsigned stride = gridDim.x * blockDim.x;
@@ -179,7 +201,15 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __rest
             }
             acc = fmaf(wy[a], row, acc);
         }
-        gx[i] = acc;
+        if (POOL) {          // feature_pool_bwd_kernel's values: g * (1 / 2) to both raw elements, added to what is there on request
+            float2* dst = reinterpret_cast<float2*>(gx) + i;
+            const float o = acc * 0.5f;
+            float2 w = make_float2(o, o);
+            if (accumulate) { const float2 old = *dst; w.x = old.x + o; w.y = old.y + o; }
+            *dst = w;
+        } else {
+            gx[i] = acc;
+        }
     }
 }
 
@@ -187,8 +217,9 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __rest
 // output columns 8j-1 .. 8j+8 of four output rows: two aligned float4 plus the two border columns per row - sixteen load
 // instructions for four results instead of sixty-four.  The per-element sums run in the scalar kernel's order (rows outer,
 // columns inner, zero-weight taps skipped): bit-identical results.
+template <bool POOL>
 __global__ void __launch_bounds__(256) upsample2x_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                 int64_t planes, int H, int W) {
+                                                                 int64_t planes, int H, int W, int accumulate) {
     const int OH = 2 * H, OW = 2 * W, W4 = W / 4;
     const unsigned n = (unsigned)(planes * H * W4);
     const unsigned stride = gridDim.x * blockDim.x;
@@ -233,7 +264,19 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_vec_kernel(const float* __
                 acc[e] = fmaf(wy[a], row, acc[e]);
             }
         }
-        reinterpret_cast<float4*>(gx)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (POOL) {
+            float4* dst = reinterpret_cast<float4*>(gx) + 2 * (int64_t)i;
+            float4 lo = make_float4(acc[0] * 0.5f, acc[0] * 0.5f, acc[1] * 0.5f, acc[1] * 0.5f);
+            float4 hi = make_float4(acc[2] * 0.5f, acc[2] * 0.5f, acc[3] * 0.5f, acc[3] * 0.5f);
+            if (accumulate) {
+                const float4 a = dst[0], b = dst[1];
+                lo.x = a.x + lo.x; lo.y = a.y + lo.y; lo.z = a.z + lo.z; lo.w = a.w + lo.w;
+                hi.x = b.x + hi.x; hi.y = b.y + hi.y; hi.z = b.z + hi.z; hi.w = b.w + hi.w;
+            }
+            dst[0] = lo; dst[1] = hi;
+        } else {
+            reinterpret_cast<float4*>(gx)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
     }
 }
 
@@ -325,26 +368,57 @@ __global__ void __launch_bounds__(256) feature_pool_bwd_kernel(const float* __re
         return LOCATE_OK;                                                                                        \
     }
 
+template <bool POOL>
+static void launch_upsample_fwd(const float* a, float* b, int64_t planes, int H, int W, hipStream_t st) {
+    const int al = POOL ? 31 : 15;          // (the pooled form reads 32-byte groups of raw elements)
+    if ((W & 3) == 0 && W >= 8 && ((uintptr_t)a & al) == 0 && ((uintptr_t)b & 15) == 0)
+        upsample2x_fwd_tile_kernel<POOL><<<stream_grid(planes * H * (W / 4), 256), 256, 0, st>>>(a, b, planes, H, W);
+    else if ((W & 1) == 0 && ((uintptr_t)b & 15) == 0 && (!POOL || ((uintptr_t)a & 7) == 0))
+        upsample2x_fwd_vec_kernel<POOL><<<stream_grid(planes * 2 * H * (W / 2), 256), 256, 0, st>>>(a, b, planes, H, W);
+    else
+        upsample2x_fwd_kernel<POOL><<<stream_grid(planes * 4 * H * W, 256), 256, 0, st>>>(a, b, planes, H, W);
+}
+template <bool POOL>
+static void launch_upsample_bwd(const float* a, float* b, int64_t planes, int H, int W, int accumulate, hipStream_t st) {
+    if ((W & 3) == 0 && W >= 8 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0)
+        upsample2x_bwd_vec_kernel<POOL><<<stream_grid(planes * H * (W / 4), 256), 256, 0, st>>>(a, b, planes, H, W, accumulate);
+    else
+        upsample2x_bwd_kernel<POOL><<<stream_grid(planes * H * W, 256), 256, 0, st>>>(a, b, planes, H, W, accumulate);
+}
+
 // x: [planes, H, W] -> y: [planes, 2H, 2W]
 LOCATE_API int locate_upsample2x_fwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
     LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_upsample2x_fwd: bad shape");
-    if ((W & 3) == 0 && W >= 8 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0)
-        upsample2x_fwd_tile_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
-    else if ((W & 1) == 0 && ((uintptr_t)b & 15) == 0)
-        upsample2x_fwd_vec_kernel<<<stream_grid(planes * 2 * H * (W / 2), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
-    else
-        upsample2x_fwd_kernel<<<stream_grid(planes * 4 * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    launch_upsample_fwd<false>(a, b, planes, H, W, as_stream(stream));
     LOCATE_LAUNCH_CHECK("locate_upsample2x_fwd");
     return LOCATE_OK;
 }
 // gy: [planes, 2H, 2W] -> gx: [planes, H, W]
 LOCATE_API int locate_upsample2x_bwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
     LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_upsample2x_bwd: bad shape");
-    if ((W & 3) == 0 && W >= 8 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0)
-        upsample2x_bwd_vec_kernel<<<stream_grid(planes * H * (W / 4), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
-    else
-        upsample2x_bwd_kernel<<<stream_grid(planes * H * W, 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    launch_upsample_bwd<false>(a, b, planes, H, W, 0, as_stream(stream));
     LOCATE_LAUNCH_CHECK("locate_upsample2x_bwd");
+    return LOCATE_OK;
+}
+// FeaturePooling(r = 2) + bilinear x2 upsample in one launch (the generator's skip branch, libs/scale.py:7-16,37-38):
+// x: the RAW tensor, 2 * planes * H * W elements (8-byte aligned) -> y: [planes, 2H, 2W]; bit for bit locate_feature_pool_fwd(r = 2)
+// followed by locate_upsample2x_fwd
+LOCATE_API int locate_pool2_upsample2x_fwd(const float* x, float* y, int64_t planes, int H, int W, void* stream) {
+    LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31) && ((uintptr_t)x & 7) == 0,
+                   "locate_pool2_upsample2x_fwd: bad shape or unaligned input");
+    launch_upsample_fwd<true>(x, y, planes, H, W, as_stream(stream));
+    LOCATE_LAUNCH_CHECK("locate_pool2_upsample2x_fwd");
+    return LOCATE_OK;
+}
+// its adjoint: gy [planes, 2H, 2W] -> gx, the RAW gradient of 2 * planes * H * W elements (accumulate != 0: added to what is there)
+LOCATE_API int locate_pool2_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int accumulate, void* stream) {
+    LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31) && ((uintptr_t)gx & 7) == 0,
+                   "locate_pool2_upsample2x_bwd: bad shape or unaligned output");
+    if ((W & 3) == 0 && W >= 8 && ((uintptr_t)gx & 31) != 0)          // (the four-wide kernel writes 32-byte groups)
+        upsample2x_bwd_kernel<true><<<stream_grid(planes * H * W, 256), 256, 0, as_stream(stream)>>>(gy, gx, planes, H, W, accumulate);
+    else
+        launch_upsample_bwd<true>(gy, gx, planes, H, W, accumulate, as_stream(stream));
+    LOCATE_LAUNCH_CHECK("locate_pool2_upsample2x_bwd");
     return LOCATE_OK;
 }
 // x: [planes, H, W] -> y: [planes, H/2, W/2]

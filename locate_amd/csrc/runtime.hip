@@ -14,7 +14,7 @@ void locate_set_error(const char* fmt, ...) {
 
 LOCATE_API const char* locate_last_error(void) { return g_last_error; }
 
-LOCATE_API int locate_abi_version(void) { return 9; }   // 9: fused RootTanh epilogues on every map (act_out, mul_pre, out_absmax; locate_conv_dgrad takes act_epilogue); 8: window panels / window kernels (panel format bit 2, precision bit 4, locate_conv_win_ok, pack passes); 7: direct panel re-packing (locate_conv_pack_job weight_absmax, Nadam record with absmax words), deferred / call-aligned split reductions; 6: locate_add3, locate_wgrad_batch*; 5: fp16-piece contractions (precision 2, panel format bit, absmax words); 4: batched finalisers
+LOCATE_API int locate_abi_version(void) { return 10; }   // 10: locate_pool2_upsample2x_fwd / _bwd; 9: fused RootTanh epilogues on every map (act_out, mul_pre, out_absmax; locate_conv_dgrad takes act_epilogue); 8: window panels / window kernels (panel format bit 2, precision bit 4, locate_conv_win_ok, pack passes); 7: direct panel re-packing (locate_conv_pack_job weight_absmax, Nadam record with absmax words), deferred / call-aligned split reductions; 6: locate_add3, locate_wgrad_batch*; 5: fp16-piece contractions (precision 2, panel format bit, absmax words); 4: batched finalisers
 
 // Fills name (<= name_len bytes), compute-unit count and wavefront size of the current device.
 // The library only ships gfx950 code objects; callers use this to fail loudly on anything else.

@@ -521,8 +521,12 @@ class Block(nn.Module):
             # three consumers (identity half of the concatenation, its 1x1 conv, the conv branch's norm): one summing launch
             skip_in, conv_alias, conv_in = ops.fork3(function_input)
         skip = skip_in
-        for i, stage in enumerate(stages):
-            skip = stage(skip, conv_alias=conv_alias) if (i == 0 and conv_alias is not None) else stage(skip)
+        if (len(stages) == 2 and isinstance(stages[0], FeaturePooling) and isinstance(stages[1], Upsample2x)
+                and ops.pool_upsample_ok(skip, stages[0].out_features)):
+            skip = ops.pool_upsample(skip, stages[0].out_features)      # one launch, the pooled map is never stored
+        else:
+            for i, stage in enumerate(stages):
+                skip = stage(skip, conv_alias=conv_alias) if (i == 0 and conv_alias is not None) else stage(skip)
         out = self.res_module_i(skip, conv_in, scales[0])
         for gate, scale in zip(self._gates, scales[1:]):
             out = gate(out, scale=scale)

@@ -956,6 +956,44 @@ class Upsample2xFn(torch.autograd.Function):
         return gx
 
 
+class PoolUpsampleFn(torch.autograd.Function):
+    """FeaturePooling to half the channels followed by the bilinear x2 upsample (the skip branch of a generator block,
+    libs/scale.py:7-16,37-38) in one launch each way; the pooled map is never stored.  Bit for bit the two separate ops."""
+
+    @staticmethod
+    def forward(ctx, x, slot=None):
+        ctx.slot = slot
+        x = _c(x, "feature pooling input")
+        B, C, H, W = x.shape
+        y = torch.empty(B, C // 2, 2 * H, 2 * W, dtype=x.dtype, device=x.device)
+        check(lib().locate_pool2_upsample2x_fwd(_p(x), _p(y), B * (C // 2), H, W, _stream()), "locate_pool2_upsample2x_fwd")
+        ctx.in_shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.in_shape
+        g = _c(g)
+        if ctx.slot is not None:
+            gx, acc = ctx.slot.claim(g, ctx.in_shape)
+        else:
+            gx, acc = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device), 0
+        check(lib().locate_pool2_upsample2x_bwd(_p(g), _p(gx), B * (C // 2), H, W, acc, _stream()), "locate_pool2_upsample2x_bwd")
+        return gx, None
+
+
+def pool_upsample_ok(x, out_features):
+    return x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] == 2 * out_features and POOL_UPSAMPLE[0]
+
+
+def pool_upsample(x, out_features):
+    """feature_pool(x, out_features) then upsample2x, fused (C == 2 * out_features)."""
+    return PoolUpsampleFn.apply(x, _slot_of(x) if x.is_contiguous() else None)
+
+
+POOL_UPSAMPLE = [os.environ.get("LOCATE_POOL_UPSAMPLE", "1") != "0"]
+
+
 class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slot=None):

@@ -493,6 +493,34 @@ def test_conv_window_form_stacked_calls_and_repack(monkeypatch):
     ops._WIN_CACHE.clear()
 
 
+@pytest.mark.parametrize("shape", [(2, 768, 4, 4), (3, 384, 8, 8), (2, 96, 32, 32), (1, 6, 5, 7), (2, 10, 3, 6), (5, 4, 1, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_pool_upsample_equals_the_two_launches(shape):
+    """FeaturePooling(C / 2) + bilinear x2 upsample in one launch each way (the generator's skip branch, libs/scale.py:7-16,37-38)
+    against the two separate ops: output and input gradient bit for bit - with and without a second consumer of the input adding
+    into the same gradient buffer (ops.fork).  Sizes walk the tile / four-wide / scalar kernels and odd widths."""
+    from locate_amd import ops
+    torch.manual_seed(2)
+    x0 = torch.randn(shape)
+    B, C, H, W = shape
+    g0 = torch.randn(B, C // 2, 2 * H, 2 * W)
+    for forked in (False, True):
+        res = []
+        for fused in (True, False):
+            x = x0.to(dev()).requires_grad_(True)
+            src = x * 1.0
+            if forked:
+                src, other = ops.fork(src)
+            y = ops.pool_upsample(src, C // 2) if fused else ops.upsample2x(ops.feature_pool(src, C // 2))
+            loss_extra = (ops.root_tanh(other) * 0.25).sum() if forked else 0.0
+            ops.reset_backward_state()
+            torch.autograd.backward([y, loss_extra] if forked else [y], [g0.to(dev()), torch.ones((), device=dev())] if forked else [g0.to(dev())])
+            res.append((y.detach().clone(), x.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]), ("forward", forked)
+        assert torch.equal(res[0][1], res[1][1]), ("input gradient", forked)
+        assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
+
+
 ACT_LINK_CASES = [
     # (conv class name, cin, mid, cout, kernel, stride, pad, batch, H)  - conv_0 (k x k) -> RootTanh -> conv_1 (1 x 1)
     ("ConvTranspose2d", 192, 192, 96, 4, 2, 1, 64, 16),      # tall tiles, four sub-pixel phases; conv_1 single-tap window form
