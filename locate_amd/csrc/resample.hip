@@ -295,6 +295,30 @@ __global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restri
     }
 }
 
+// W a multiple of 8: one thread per FOUR consecutive outputs of a row - two 32-byte row segments in, one 16-byte store out (the
+// scalar kernel above issues four 4-byte loads per output); the same sum per output: bit-identical.
+__global__ void __launch_bounds__(256) avgpool2_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
+                                                               int H, int W) {
+    const int OH = H / 2, OW4 = W / 8;
+    const unsigned n = (unsigned)(planes * OH * OW4);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const DivU32 dw((unsigned)OW4), dh((unsigned)OH);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned t, j, p, oy;
+        dw.divmod(i, t, j);
+        dh.divmod(t, p, oy);
+        const float* r0 = x + (int64_t)p * H * W + (int64_t)(2 * oy) * W + 8 * j;
+        const float4 a0 = reinterpret_cast<const float4*>(r0)[0], a1 = reinterpret_cast<const float4*>(r0)[1];
+        const float4 b0 = reinterpret_cast<const float4*>(r0 + W)[0], b1 = reinterpret_cast<const float4*>(r0 + W)[1];
+        float4 o;
+        o.x = ((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f;
+        o.y = ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f;
+        o.z = ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f;
+        o.w = ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f;
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
 __global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                            int64_t planes, int H, int W, int accumulate) {
     const int OH = H / 2, OW = W / 2;
@@ -422,7 +446,15 @@ LOCATE_API int locate_pool2_upsample2x_bwd(const float* gy, float* gx, int64_t p
     return LOCATE_OK;
 }
 // x: [planes, H, W] -> y: [planes, H/2, W/2]
-RESAMPLE_ENTRY(locate_avgpool2_fwd, avgpool2_fwd_kernel, planes * (H / 2) * (W / 2))
+LOCATE_API int locate_avgpool2_fwd(const float* a, float* b, int64_t planes, int H, int W, void* stream) {
+    LOCATE_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * 4 * H * W < (1ll << 31), "locate_avgpool2_fwd: bad shape");
+    if ((W & 7) == 0 && (H & 1) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0)
+        avgpool2_fwd_vec_kernel<<<stream_grid(planes * (H / 2) * (W / 8), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    else
+        avgpool2_fwd_kernel<<<stream_grid(planes * (H / 2) * (W / 2), 256), 256, 0, as_stream(stream)>>>(a, b, planes, H, W);
+    LOCATE_LAUNCH_CHECK("locate_avgpool2_fwd");
+    return LOCATE_OK;
+}
 // gy: [planes, H/2, W/2] -> gx: [planes, H, W]   (H, W are the INPUT sizes of the forward)
 // accumulate != 0: gx += ... (the second backward kernel of a forked tensor, see ops.fork)
 LOCATE_API int locate_avgpool2_bwd(const float* a, float* b, int64_t planes, int H, int W, int accumulate, void* stream) {
