@@ -688,12 +688,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgParams p) {
 // stage covers twice the reduction depth at the same per-thread work, each wave owns half the rows of a four-wave tile, and two
 // waves per SIMD cover each other's waits: for launches that cannot put more than one block on a CU anyway (mid-sized layers:
 // a hundred-odd tiles), where a lone four-wave block walks its K loop at ~1.2 us per 16-deep stage.
-// Resident blocks per CU: one eight-wave block; two of the tall tiles; FOUR of the 96 x 128 two-piece tiles (128 VGPRs, 8 bytes of
+// Resident blocks per CU: one eight-wave block; two of the tall tiles; FOUR of the 96 x 128 and 64 x 128 two-piece tiles (117 - 128 VGPRs, at most 8 bytes of
 // scratch: the 96-channel stage is 2048 blocks of 24 short K steps - more waves in flight are worth more there than registers:
 // 0.108 - 0.112 -> 0.104 - 0.105 ms forward, same call, alternating); three otherwise (the other small tiles spill at 128)
 #define IG_FOUR_BLOCKS_TILES 3
+#define IG_FOUR_BLOCKS_MIN 2
 template <int WGM, int WGN, int TM, int TN, int NP, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : ((WGM * TM * TN == IG_FOUR_BLOCKS_TILES && NP <= 2) ? 4 : 3)))) conv_igemm_bx6_kernel(const IgParams p) {
+__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 1 : (WGM * TM > 4 ? 2 : ((WGM * TM * TN <= IG_FOUR_BLOCKS_TILES && WGM * TM * TN >= IG_FOUR_BLOCKS_MIN && NP <= 2) ? 4 : 3)))) conv_igemm_bx6_kernel(const IgParams p) {
     constexpr int BK = 4 * NW, KB = BK / 8, KS = BK / 16, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;

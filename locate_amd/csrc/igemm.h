@@ -325,8 +325,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgParams& p, const IgPhase&
                         const float v = stage[nl * 33 + ml];
                         if (nt0 + nl < N && mt0 + ml < p.M) out_base[(long long)(b0 + bl) * obs + (long long)(mt0 + ml) * plane + pix] = v;
                     }
-                } else if (TM * TN <= 2 && p.mul_pre != nullptr) {
-                    // the fused forms (see below).  (Instantiations with few tiles per wave - the ones small maps are launched
+                } else if (WGM * WGN == 8 && TM * TN <= 2 && p.mul_pre != nullptr) {
+                    // the fused forms (see below).  (The eight-wave instantiations - the ones small maps are launched
                     // with; the large tiles' register budget has no room for this and takes the rolled loop at the end.)
                     // The sixteen pre-activation loads of the tile go out together (one after the other
                     // they were sixteen exposed round trips: 33 us for a 16-block launch that takes 17 without the epilogue); the
