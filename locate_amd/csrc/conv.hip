@@ -1576,6 +1576,7 @@ static bool win_finish(IgParams& p, PackBatch& batch, int fmt, float* panel, siz
         const long long N1 = (long long)p.B * p.H * p.W;
         bn = 128;
         bm = ((N1 + 127) / 128) * ((p.M + 63) / 64) >= 256 ? 64 : 32;
+        if (round_up(p.M, 64) != round_up(p.M, 32)) bm = 32;          // (the panel is round_up(M, 32) columns wide: M = 96 has no 64-row tiling)
     }
     {   // (debug library: force a tile - LOCATE_WIN_BM rows, LOCATE_WIN_BN columns)
         const int fbm = knob_int("LOCATE_WIN_BM", 0), fbn = knob_int("LOCATE_WIN_BN", 0);

@@ -256,6 +256,13 @@ __global__ void __launch_bounds__(256, 2) conv_win_kernel(const IgParams p) {
     };
 
     // ---- prologue: the zero chunks, window 0 in full, weight tile 0; then the loads of weight tile 1 and of window 1's first part
+    if (Tp == 1 && (C8G % U) != 0) {
+        // a single-tap window whose last stage holds fewer than U channel groups: the missing groups' chunks are never written (their
+        // items go to the trash slot) but ARE read - against zero weight rows - and what an untouched LDS word holds need not be a
+        // finite number (0 x NaN: the 24 -> 12 channel 1x1 layer of the tiny test network came out NaN): clear both images once
+        for (int e = tid; e < 2 * NP * WINC * SP; e += NT) smem[A_U4 + e] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
     if (tid < 2 * NP) smem[A_U4 + tid * WINC * SP + SP - 1] = make_uint4(0u, 0u, 0u, 0u);       // slot SP - 1 of group 0, every buffer / piece
     __syncthreads();               // the item table
     if (nsteps > 0) {

@@ -406,6 +406,10 @@ WINDOW_CASES = [
     ("convT", 384, 192, 1, 1, 0, 4, 8, 8),      # transposed single tap, split-K (few tiles)
     ("conv", 96, 160, 1, 1, 0, 3, 2, 64),       # single tap on a 2 x 64 map (flat pixel runs), ragged M
     ("conv", 48, 48, 1, 1, 0, 5, 2, 2),         # 4-pixel maps: 32 images per tile, partial tile
+    ("convT", 24, 12, 1, 1, 0, 8, 16, 16),      # single tap, THREE 8-channel groups under four per stage: the padded group's window
+                                                # chunks are read against zero weights and must be finite (cleared LDS; was NaN)
+    ("conv", 40, 96, 1, 1, 0, 4, 16, 16),       # single tap, M = 96: the panel is 96 columns wide - 32-row tiles, not 64; five groups
+    ("convT", 192, 96, 1, 1, 0, 64, 32, 32),    # ... at the size where the 64-row tile would have been picked
 ]
 
 
