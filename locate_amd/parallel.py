@@ -305,7 +305,11 @@ class GradAllReducer:
         h = zlib.crc32(repr(sig).encode()) & 0x7fffffff
         dev = self.params[self.buckets[b][0]].device if self.buckets[b] else torch.device("cpu")
         t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        # (asynchronous like every bucket, then joined: all of this communicator's collectives go through the process group's one
+        # stream in issue order, none runs on the caller's stream beside them)
+        work = dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        if work is not None:
+            work.wait()
         hi, lo = t.tolist()
         if hi != h or -lo != h:
             raise RuntimeError("data-parallel ranks disagree on which parameters of bucket %d carry a gradient (this rank: %d "
