@@ -130,6 +130,43 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
     return t;
 }
+// Sum of channel c over the batch slice [b0, b0 + nb) of g [B, C, hw] by ONE wave, for slices of at most 1024 (16-byte) elements:
+// the arithmetic of a 1024-thread block in which every thread holds at most one element - a butterfly per 64 elements, the sixteen
+// wave results added in order (block_sum) - so a kernel that gives such a slice to a wave instead of a block returns the same bits.
+// (Bias gradients on 1x1 ... 4x4 maps: 64 ... 768 elements per channel; a block of 1024 threads per channel was 4 400 blocks of
+// mostly idle lanes and two barriers each.)
+__device__ __forceinline__ float channel_sum_wave(const float* __restrict__ g, int64_t batch_stride, int c, int hw, int b0, int nb,
+                                                  bool vec, int lane) {
+    float total = 0.0f;
+    if (vec) {
+        const int hw4 = hw >> 2, n = nb * hw4;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int i = k0 + lane;
+            float v = 0.0f;
+            if (i < n) {
+                const int b = i / hw4, r = i - b * hw4;
+                const float4 q = reinterpret_cast<const float4*>(g + (int64_t)(b0 + b) * batch_stride + (int64_t)c * hw)[r];
+                v = 0.0f + ((q.x + q.y) + (q.z + q.w));
+            }
+            total += wave_sum(v);
+        }
+    } else {
+        const int n = nb * hw;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int i = k0 + lane;
+            float v = 0.0f;
+            if (i < n) {
+                const int b = i / hw, r = i - b * hw;
+                v = 0.0f + g[(int64_t)(b0 + b) * batch_stride + (int64_t)c * hw + r];
+            }
+            total += wave_sum(v);
+        }
+    }
+    return total;
+}
+// whether a slice of nb batch elements of one channel takes that form
+__host__ __device__ __forceinline__ bool channel_sum_small(int nb, int hw, bool vec) { return (long long)nb * (vec ? hw >> 2 : hw) <= 1024; }
+
 // q = i / d, r = i % d for 32-bit unsigned operands: shift/mask when d is a power of two (every spatial size and most
 // channel counts of this model), one 32-bit division otherwise.  The kernels' flat element indices stay below 2^31
 // (checked by the host entries), so none of them needs the ~100-instruction 64-bit division in its inner loop.

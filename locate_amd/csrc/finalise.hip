@@ -164,14 +164,25 @@ __global__ void __launch_bounds__(1024) fin_channel_sums_kernel(const FinBatch b
     const FinRec& R = batch.r[ri];
     const int bx = (int)blockIdx.x - R.i[5];
     const int B = R.i[0], C = R.i[1], hw = R.i[2], slices = R.i[3], per_slice = R.i[4];
-    const int c = bx % C, sl = bx / C;
     const float* __restrict__ g = static_cast<const float*>(R.p[0]);
     float* __restrict__ out = static_cast<float*>(const_cast<void*>(slices > 1 ? R.p[2] : R.p[1]));
     const int64_t batch_stride = R.l[0];
+    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (channel_sum_small(per_slice, hw, vec)) {          // sixteen (channel, slice) pairs per block, a wave each (channel_sum_kernel's form)
+        const int C16 = (C + 15) / 16;
+        const int sl = bx / C16, c = (bx - sl * C16) * 16 + ((int)threadIdx.x >> 6);
+        const int b0 = sl * per_slice;
+        const int nb = min(per_slice, B - b0);
+        if (c < C) {
+            const float t = nb > 0 ? channel_sum_wave(g, batch_stride, c, hw, b0, nb, vec, threadIdx.x & 63) : 0.0f;
+            if ((threadIdx.x & 63) == 0) out[(int64_t)sl * C + c] = t;
+        }
+        return;
+    }
+    const int c = bx % C, sl = bx / C;
     const int b0 = sl * per_slice;
     const int nb = min(per_slice, B - b0);
     float acc = 0.0f;
-    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     if (nb > 0) {
         if (vec) {
             const int hw4 = hw >> 2;
@@ -284,7 +295,11 @@ LOCATE_API int locate_fin_channel_sums(const void* records, int n, void* stream)
             R.i[3] = slices;
             R.i[4] = (R.i[0] + slices - 1) / slices;
             R.i[5] = blocks;
-            R.i[6] = R.i[1] * slices;
+            {
+                const float* g = static_cast<const float*>(R.p[0]);
+                const bool vec = (R.i[2] & 3) == 0 && (R.l[0] & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+                R.i[6] = (channel_sum_small(R.i[4], R.i[2], vec) ? (R.i[1] + 15) / 16 : R.i[1]) * slices;
+            }
             blocks += R.i[6];
             any_split = any_split || slices > 1;
         }

@@ -659,11 +659,21 @@ LOCATE_API int locate_fin_norm_channels(const void* records, int n, void* stream
 __global__ void __launch_bounds__(1024) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int C,
                                                            int hw, int64_t batch_stride, int per_slice) {
     __shared__ float scratch[16];
+    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (channel_sum_small(per_slice, hw, vec)) {          // sixteen channels per block, a wave each (common.h: same bits)
+        const int c = blockIdx.x * 16 + ((int)threadIdx.x >> 6);
+        const int b0 = blockIdx.y * per_slice;
+        const int nb = min(per_slice, B - b0);
+        if (c < C) {
+            const float t = nb > 0 ? channel_sum_wave(g, batch_stride, c, hw, b0, nb, vec, threadIdx.x & 63) : 0.0f;
+            if ((threadIdx.x & 63) == 0) out[(int64_t)blockIdx.y * C + c] = t;
+        }
+        return;
+    }
     const int c = blockIdx.x;
     const int b0 = blockIdx.y * per_slice;
     const int nb = min(per_slice, B - b0);
     float acc = 0.0f;
-    const bool vec = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     if (nb > 0) {
         if (vec) {
             const int hw4 = hw >> 2;
@@ -713,15 +723,18 @@ LOCATE_API int locate_channel_sum(const float* g, float* out, int B, int C, int 
     LOCATE_REQUIRE(B > 0 && C > 0 && hw > 0 && batch_stride >= (int64_t)C * hw && (int64_t)B * hw < (1ll << 31),
                    "locate_channel_sum: bad shape");
     const int slices = channel_sum_slices(B, C, hw);
+    const bool vec_h = (hw & 3) == 0 && (batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     if (slices == 1) {
-        channel_sum_kernel<<<dim3(C, 1), 1024, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride, B);
+        const int gx = channel_sum_small(B, hw, vec_h) ? (C + 15) / 16 : C;
+        channel_sum_kernel<<<dim3(gx, 1), 1024, 0, as_stream(stream)>>>(g, out, B, C, hw, batch_stride, B);
         LOCATE_LAUNCH_CHECK("locate_channel_sum");
         return LOCATE_OK;
     }
     LOCATE_REQUIRE(workspace, "locate_channel_sum: missing workspace");
     float* part = static_cast<float*>(workspace);
     const int per_slice = (B + slices - 1) / slices;
-    channel_sum_kernel<<<dim3(C, slices), 1024, 0, as_stream(stream)>>>(g, part, B, C, hw, batch_stride, per_slice);
+    const int gxs = channel_sum_small(per_slice, hw, vec_h) ? (C + 15) / 16 : C;
+    channel_sum_kernel<<<dim3(gxs, slices), 1024, 0, as_stream(stream)>>>(g, part, B, C, hw, batch_stride, per_slice);
     LOCATE_LAUNCH_CHECK("locate_channel_sum");
     channel_sum_final_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(part, out, C, slices);
     LOCATE_LAUNCH_CHECK("locate_channel_sum(final)");
