@@ -294,6 +294,8 @@ CONV_CASES = [
     ("conv", 260, 64, 3, 1, 1, 2, 8, 8),      # ragged K = 2340, split count capped at 64: trailing splits own no stage
     ("convT", 296, 64, 4, 2, 1, 2, 4, 4),     # adjoint phases with K = 1184 = Kpad exactly (no padding rows before the tail)
     ("conv", 128, 128, 1, 1, 0, 4, 8, 8),     # K = Kpad = 128: 8 stages, the split threshold
+    ("conv", 342, 192, 3, 1, 1, 3, 6, 8),     # weight gradient on the tall 192 x 128 tile (M % 192 == 0, 25 column tiles): ragged R = 3078, odd batch
+    ("convT", 384, 96, 4, 2, 1, 2, 4, 4),     # ... transposed (R's rows are the transposed layer's inputs: M = 384, two tall row tiles)
     # maps so small that most taps only ever see padding (the contraction runs over the useful taps only)
     ("conv", 64, 64, 5, 2, 2, 6, 2, 2),       # 2x2 -> 1x1: 4 of 25 taps (the discriminator's last block)
     ("conv", 32, 48, 3, 1, 1, 5, 1, 1),       # 3x3 p1 on a 1x1 map: the centre tap only (the discriminator's head)
