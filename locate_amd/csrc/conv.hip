@@ -2729,7 +2729,10 @@ static void wgrad_plan(const ConvGeom& g, int* bm, int* nsplit, int* chunk, int*
 }
 
 static int wgrad_reduce_zp(int nsplit, int64_t n) {
-    if (nsplit >= 64 && n < (1 << 16)) return 16;      // few outputs, many slabs: 16 threads share one output element
+    // few outputs, many slabs: 16 threads share one output element - below 4096 elements only: from there on the four-way form with
+    // its 16-byte accesses is faster (same-call A/B of the step, threshold 65536 / 16384 / 4096 / 1024: 8.97, 8.96 / 8.95, 8.96 / 8.92,
+    // 8.94 / 8.94, 8.96 ms)
+    if (nsplit >= 64 && n < knob_int("LOCATE_ZP16_MAX_N", 1 << 12)) return 16;
     return (nsplit >= 16 && n < (1 << 20)) ? 4 : 1;
 }
 static int wgrad_reduce_grid(int64_t n, int nsplit) {
